@@ -1,0 +1,51 @@
+"""Problem instances for the batched env (host side, numpy only).
+
+generate_instance restates the draw order of the reference generator
+(env/task_env.py:57-114) for fixed sizes: with a seeded numpy Generator the order is
+depot random((1,2)) :67 -> cost random((A,1)) :68 (unused, but it advances the stream)
+-> task xy random((T,2)) :69 -> requirements integers(1, max_coalition_size+1, T) :71;
+durations are the constant max_duration :70.  (When agents_range/tasks_range are tuples
+the reference first draws the sizes :59,:63; the batched env needs one (A,T) per batch,
+exactly like one driver round does, driver.py:114-117.)
+"""
+import json
+import os
+
+import numpy as np
+
+
+def generate_instance(A, T, seed, max_coalition_size=5, max_duration=5.0):
+    rng = np.random.default_rng(seed)
+    depot = rng.random((1, 2))[0]
+    rng.random((A, 1))  # agents' cost: drawn, never used (env/task_env.py:68,97)
+    task_xy = rng.random((T, 2))
+    req = rng.integers(1, max_coalition_size + 1, T).astype(np.int32)
+    dur = np.full(T, float(max_duration), dtype=np.float64)
+    return dict(depot=depot, task_xy=task_xy, req=req, dur=dur)
+
+
+def generate_batch(B, A, T, base_seed=0, first=0, max_coalition_size=5, max_duration=5.0):
+    """Instances base_seed+first .. base_seed+first+B-1 stacked as depot[B,2], task_xy[B,T,2], req[B,T], dur[B,T]."""
+    depot = np.empty((B, 2), np.float64)
+    task_xy = np.empty((B, T, 2), np.float64)
+    req = np.empty((B, T), np.int32)
+    for b in range(B):
+        rng = np.random.default_rng(base_seed + first + b)
+        depot[b] = rng.random((1, 2))[0]
+        rng.random((A, 1))
+        task_xy[b] = rng.random((T, 2))
+        req[b] = rng.integers(1, max_coalition_size + 1, T)
+    dur = np.full((B, T), float(max_duration), dtype=np.float64)
+    return dict(depot=depot, task_xy=task_xy, req=req, dur=dur)
+
+
+def load_instances_npz(path):
+    """Fixture format of tests/golden/instances_20A50T.npz (depot[N,2], task_xy[N,T,2], req[N,T], dur[N,T], A)."""
+    z = np.load(path)
+    return dict(depot=z["depot"], task_xy=z["task_xy"], req=z["req"].astype(np.int32), dur=z["dur"]), int(z["A"])
+
+
+def load_routes_json(path):
+    """Preset routes {instance: [[0, k1, k2, ..., 0], ...]} in CTAS-D node numbering (baselines/CTAS-D.py:10-33)."""
+    with open(path) as f:
+        return {int(k): v for k, v in json.load(f).items()}
