@@ -1,0 +1,229 @@
+"""BatchedTaskEnv -- host-side face of the HIP env (B independent TaskEnv instances on one GPU).
+
+Mirrors what worker.py:41-112 does around one reference TaskEnv, for a whole batch:
+
+    env = BatchedTaskEnv(B, A, T, device="cuda:0")
+    env.load_instances(depot, task_xy, req, dur)        # generate_env outputs  (env/task_env.py:57-114)
+    obs = env.reset(seeds)                              # reset+clear_decisions (:116-140) -> first decision
+    while obs.active.any():
+        logp = policy(obs.tasks, obs.agents, obs.mask)  # attention.py:288-297 input contract
+        obs = env.step(actions)                         # TaskEnv.step :326-342 + worker.py:74-85
+    env.summary()                                       # reward + perf metrics, worker.py:87,103-108
+
+torch is used for device memory and streams only; all simulation work happens in
+libdcmrta_hip.so (hand-written gfx950 kernels) through the C ABI of include/dcmrta_env.h.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DcmError, DcmParams, check
+
+SUMMARY_COLUMNS = ("reward", "n_finished", "success_rate", "makespan", "time_cost", "waiting_time", "travel_dist",
+                   "efficiency")
+
+
+@dataclass
+class Observation:
+    """Inputs of the attention policy for every env (SURVEY §8b policy contract)."""
+    agents: torch.Tensor  # f32[B,A,6]
+    tasks: torch.Tensor   # f32[B,T+1,5]
+    mask: torch.Tensor    # bool[B,T+1], True = forbidden
+    leader: torch.Tensor  # i32[B], -1 when the env's episode is over
+    active: torch.Tensor  # bool[B]
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedTaskEnv:
+    def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0):
+        self._h = None
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise DcmError("BatchedTaskEnv runs on a HIP device only (device='cuda:N'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise DcmError("no HIP device visible to torch; BatchedTaskEnv has no CPU fallback")
+        self.B, self.A, self.T = int(n_envs), int(n_agents), int(n_tasks)
+        self.max_waiting_time, self.max_time = float(max_waiting_time), float(max_time)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, 0, 0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_create(C.byref(p), C.byref(h)))
+        self._h = h
+        B, A, T = self.B, self.A, self.T
+        dev = self.device
+        self._agents = torch.empty((B, A, 6), dtype=torch.float32, device=dev)
+        self._tasks = torch.empty((B, T + 1, 5), dtype=torch.float32, device=dev)
+        self._mask = torch.empty((B, T + 1), dtype=torch.uint8, device=dev)
+        self._leader = torch.empty((B,), dtype=torch.int32, device=dev)
+        self._active = torch.empty((B,), dtype=torch.uint8, device=dev)
+        self._instances = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dcm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+
+    # ------------------------------------------------------------------ instances / reset
+    def load_instances(self, depot, task_xy, req, dur):
+        """depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] int in 1..5, dur[B,T] f64 (numpy or torch)."""
+        B, T = self.B, self.T
+        req_np = req.cpu().numpy() if isinstance(req, torch.Tensor) else np.asarray(req)
+        if req_np.shape != (B, T) or req_np.min() < 1 or req_np.max() > _lib.MAX_MEMBERS:
+            raise DcmError(f"req must be int[{B},{T}] with values in 1..{_lib.MAX_MEMBERS}")
+        d = self._dev(depot, torch.float64)
+        xy = self._dev(task_xy, torch.float64)
+        rq = self._dev(req, torch.int32)
+        du = self._dev(dur, torch.float64)
+        if d.shape != (B, 2) or xy.shape != (B, T, 2) or du.shape != (B, T):
+            raise DcmError("instance arrays have the wrong shape")
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_load_instances(self._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du), self._stream()))
+        self._instances = (d, xy, rq, du)  # keep alive until the kernel ran
+        return self
+
+    def reset(self, seeds, observe=True):
+        """seeds: uint64[B] per-env choice-protocol seeds (numpy/torch) or an int base seed."""
+        if isinstance(seeds, (int, np.integer)):
+            from .choice import env_seeds
+            seeds = env_seeds(int(seeds), 0, self.B)
+        if isinstance(seeds, torch.Tensor):
+            s = seeds.to(self.device).contiguous()
+        else:
+            s = torch.from_numpy(np.ascontiguousarray(seeds, dtype=np.uint64).view(np.int64)).to(self.device)
+        if s.numel() != self.B:
+            raise DcmError("seeds must have one entry per env")
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_reset(self._h, _ptr(s), self._stream()))
+        self._seeds = s
+        return self.observe() if observe else None
+
+    # ------------------------------------------------------------------ observe / step
+    def _obs(self):
+        return Observation(self._agents, self._tasks, self._mask.view(torch.bool), self._leader,
+                           self._active.view(torch.bool))
+
+    def observe(self, leader=None):
+        li = None if leader is None else self._dev(leader, torch.int32)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_observe(self._h, _ptr(self._agents), _ptr(self._tasks), _ptr(self._mask),
+                                        _ptr(self._leader), _ptr(self._active), _ptr(li), self._stream()))
+        return self._obs()
+
+    def step(self, actions, leader=None, n_followers=None, followers=None, observe=True):
+        """actions int32[B] (0 = depot, k = task k-1).  Optional injected choices for parity replays:
+        leader int32[B] (-1 = draw), n_followers int32[B] (-1 = draw), followers int16[B,4]."""
+        a = self._dev(actions, torch.int32)
+        li = None if leader is None else self._dev(leader, torch.int32)
+        nf = None if n_followers is None else self._dev(n_followers, torch.int32)
+        fo = None if followers is None else self._dev(followers, torch.int16)
+        if fo is not None and tuple(fo.shape) != (self.B, _lib.FOLLOWER_COLS):
+            raise DcmError("followers must be int16[B,4]")
+        o = (self._agents, self._tasks, self._mask, self._leader, self._active) if observe else (None,) * 5
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_step(self._h, _ptr(a), _ptr(li), _ptr(nf), _ptr(fo), *[_ptr(x) for x in o],
+                                     self._stream()))
+        return self._obs() if observe else None
+
+    def rollout_random(self, episodes=1, write_obs=True):
+        """Config-2 hot path: `episodes` full random-policy episodes per env in one persistent launch.
+        Returns steps int64[B] (device tensor)."""
+        steps = torch.empty((self.B,), dtype=torch.int64, device=self.device)
+        o = (self._agents, self._tasks, self._mask) if write_obs else (None, None, None)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_rollout_random(self._h, int(episodes), *[_ptr(x) for x in o], _ptr(steps),
+                                               self._stream()))
+        return steps
+
+    # ------------------------------------------------------------------ results
+    def summary(self):
+        """f64[B,8]: reward, n_finished, success_rate, makespan, time_cost, waiting_time, travel_dist, efficiency."""
+        out = torch.empty((self.B, 8), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_summary(self._h, _ptr(out), self._stream()))
+        return out
+
+    def status(self):
+        flags = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        dec = torch.empty((self.B,), dtype=torch.int64, device=self.device)
+        now = torch.empty((self.B,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_env_status(self._h, _ptr(flags), _ptr(dec), _ptr(now), self._stream()))
+        return dict(flags=flags, decisions=dec, now=now)
+
+    def tasks_state(self):
+        B, T, dev = self.B, self.T, self.device
+        u8 = lambda: torch.empty((B, T), dtype=torch.uint8, device=dev)
+        f8 = lambda: torch.empty((B, T), dtype=torch.float64, device=dev)
+        i4 = lambda: torch.empty((B, T), dtype=torch.int32, device=dev)
+        o = dict(finished=u8(), feasible=u8(), time_start=f8(), time_finish=f8(), sum_waiting_time=f8(), status=i4(),
+                 n_members=i4(), n_abandoned=i4())
+        with torch.cuda.device(dev):
+            check(self._lib.dcm_get_tasks(self._h, *[_ptr(v) for v in o.values()], self._stream()))
+        return o
+
+    def agents_state(self):
+        B, A, dev = self.B, self.A, self.device
+        f8 = lambda: torch.empty((B, A), dtype=torch.float64, device=dev)
+        u8 = lambda: torch.empty((B, A), dtype=torch.uint8, device=dev)
+        o = dict(sum_waiting_time=f8(), travel_dist=f8(), next_decision=f8(), arrival=f8(), x=f8(), y=f8(),
+                 returned=u8(), assigned=u8(), current=torch.empty((B, A), dtype=torch.int32, device=dev))
+        with torch.cuda.device(dev):
+            check(self._lib.dcm_get_agents(self._h, *[_ptr(v) for v in o.values()], self._stream()))
+        return o
+
+    # ------------------------------------------------------------------ snapshot (copy.deepcopy(env), worker.py:33)
+    def clone_state(self):
+        n = C.c_size_t()
+        check(self._lib.dcm_state_bytes(self._h, C.byref(n)))
+        buf = torch.empty((n.value,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_clone_state(self._h, _ptr(buf), self._stream()))
+        return buf
+
+    def restore_state(self, buf):
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_restore_state(self._h, _ptr(buf), self._stream()))
+
+    def record_bytes(self):
+        n = C.c_size_t()
+        check(self._lib.dcm_record_bytes(self._h, C.byref(n)))
+        return n.value
+
+
+def device_distance(a_xy, b_xy, device="cuda:0"):
+    """calculate_eulidean_distance + travel time on the device (known-answer test helper)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    a = torch.as_tensor(np.ascontiguousarray(a_xy), dtype=torch.float64).to(dev)
+    b = torch.as_tensor(np.ascontiguousarray(b_xy), dtype=torch.float64).to(dev)
+    ax, ay, bx, by = a[:, 0].contiguous(), a[:, 1].contiguous(), b[:, 0].contiguous(), b[:, 1].contiguous()
+    d = torch.empty_like(ax)
+    t = torch.empty_like(ax)
+    with torch.cuda.device(dev):
+        check(lib.dcm_distance(_ptr(ax), _ptr(ay), _ptr(bx), _ptr(by), _ptr(d), _ptr(t), ax.numel(),
+                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return d.cpu().numpy(), t.cpu().numpy()

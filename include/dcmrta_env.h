@@ -1,0 +1,154 @@
+/*
+ * dcmrta_env.h -- C ABI of the MI355X-native batched coalition-formation + routing env.
+ *
+ * The reference (marmotlab/DCMRTA) has no FFI on this path: its boundary is duck-typed
+ * Python (env/task_env.py class TaskEnv, driven by worker.py:41-112).  This header is
+ * the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md).  Each entry
+ * point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C symbols, every call returns 0 on success or a negative dcm_status;
+ *    dcm_last_error() returns a thread-local message for the last failure.
+ *  - every array argument is a caller-owned DEVICE pointer (tensor.data_ptr()) unless it
+ *    is marked "host"; the library never frees or retains it past the call.
+ *  - every call takes the hipStream_t to enqueue on (torch.cuda.current_stream().cuda_stream,
+ *    passed as void*) and is asynchronous with respect to the host.
+ *  - a handle is bound to one device and is not thread-safe (one host thread per GPU,
+ *    like one env per Ray actor in runner.py:74).
+ *  - there is NO CPU implementation behind this ABI: without a HIP device dcm_create fails.
+ *
+ * One "env step" = one leader decision in one env = one TaskEnv.step call
+ * (env/task_env.py:326) plus the task_update/agent_update and observation/mask
+ * construction the worker wraps around it (worker.py:57-84).
+ */
+#ifndef DCMRTA_ENV_H
+#define DCMRTA_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCM_ABI_VERSION 1
+
+typedef struct dcm_env dcm_env; /* opaque */
+
+typedef enum {
+    DCM_OK = 0,
+    DCM_ERR_INVALID = -1, /* bad argument */
+    DCM_ERR_HIP = -2,     /* HIP runtime error (message has hipGetErrorString) */
+    DCM_ERR_NO_DEVICE = -3,
+    DCM_ERR_STATE = -4    /* call not valid in the handle's current state */
+} dcm_status;
+
+/* limits of this build */
+#define DCM_MAX_AGENTS 128
+#define DCM_MAX_TASKS 1023
+#define DCM_MAX_MEMBERS 5 /* COALITION_SIZE, parameters.py:17: members <= requirement <= 5 */
+#define DCM_FOLLOWER_COLS 4
+
+/* per-env flag bits reported by dcm_env_flags() */
+#define DCM_FLAG_DONE 1u       /* episode over (terminal box of worker.py:87) */
+#define DCM_FLAG_FINISHED 2u   /* env.finished is True (env/task_env.py:366-373) */
+#define DCM_FLAG_TRUNCATED 4u  /* zero-decider guard fired (the reference would spin) */
+#define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T] */
+#define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members (masked action chosen) */
+#define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
+
+typedef struct {
+    int32_t n_envs;             /* B */
+    int32_t n_agents;           /* A, identical for every env of the batch (driver.py:114-117) */
+    int32_t n_tasks;            /* T */
+    int32_t device;             /* HIP device ordinal */
+    double max_waiting_time;    /* env/task_env.py:30 (10) */
+    double max_time;            /* MAX_TIME, parameters.py:18 (100) */
+    uint32_t flags;             /* reserved, 0 */
+    uint32_t reserved;
+} dcm_params;
+
+const char *dcm_last_error(void);
+int dcm_abi_version(void);
+
+/* TaskEnv.__init__ (env/task_env.py:9-34): allocate SoA state for B envs of (A,T). */
+int dcm_create(const dcm_params *params, dcm_env **out);
+int dcm_destroy(dcm_env *env);
+
+/* generate_env outputs (env/task_env.py:57-114) handed over as arrays:
+ * depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] i32 in 1..DCM_MAX_MEMBERS, dur[B,T] f64. */
+int dcm_load_instances(dcm_env *env, const double *depot, const double *task_xy, const int32_t *req,
+                       const double *dur, void *stream);
+
+/* reset + clear_decisions (env/task_env.py:116-140) for every env, then advance each env to its
+ * first decision point (event t=0, one group of all agents; worker.py:45-51).
+ * seeds[B] u64: per-env seed of the choice protocol; the decision counter restarts at 0. */
+int dcm_reset(dcm_env *env, const uint64_t *seeds, void *stream);
+
+/* What worker.py:54-68 builds before calling the policy, for all envs at once:
+ *   agents_out[B,A,6] f32   get_current_agent_status  (env/task_env.py:165-180)
+ *   tasks_out[B,T+1,5] f32  get_current_task_status   (env/task_env.py:182-190)
+ *   mask_out[B,T+1] u8      get_unfinished_task_mask + depot bit (:192-200, worker.py:57-61); 1 = forbidden
+ *   leader_out[B] i32       the deciding agent (worker.py:54), -1 for finished envs
+ *   active_out[B] u8        0 once the env's episode is over
+ * leader_in (nullable, [B] i32, -1 = draw): inject the leader instead of drawing it.
+ * Pure function of the state: calling it twice returns the same tensors. */
+int dcm_observe(dcm_env *env, float *agents_out, float *tasks_out, uint8_t *mask_out, int32_t *leader_out,
+                uint8_t *active_out, const int32_t *leader_in, void *stream);
+
+/* TaskEnv.step (env/task_env.py:326-342) for the current leader of every active env, followed by
+ * task_update/agent_update (worker.py:74-76) and the advance to the next decision point:
+ * next leader in the group -> next group -> check_finished (worker.py:85) -> next event
+ * (worker.py:45-51) -> terminal (worker.py:87, metrics :103-108).
+ *   actions[B] i32: 0 = depot, k = task k-1.
+ *   leader_in / nfol_in / followers_in[B,DCM_FOLLOWER_COLS] (all nullable): injected choices;
+ *   nfol_in[b] < 0 means "draw followers from the protocol".
+ * If agents_out..active_out are non-NULL the observation of the NEW decision point is written
+ * in the same launch (fused observe; leader drawn from the protocol). */
+int dcm_step(dcm_env *env, const int32_t *actions, const int32_t *leader_in, const int32_t *nfol_in,
+             const int16_t *followers_in, float *agents_out, float *tasks_out, uint8_t *mask_out,
+             int32_t *leader_out, uint8_t *active_out, void *stream);
+
+/* Config-2 hot path: every env plays `episodes` complete episodes under the uniform-random valid
+ * policy inside ONE persistent launch (worker.py:45-87 with the action drawn from slot 1 of the
+ * protocol); the observation tensors + mask are produced at every decision exactly as dcm_observe
+ * does and written to agents_out/tasks_out/mask_out (nullable: skip the stores).  Envs restart
+ * from their loaded instance between episodes; the decision counter keeps running.
+ * steps_out[B] i64: decisions taken by each env over all episodes. */
+int dcm_rollout_random(dcm_env *env, int32_t episodes, float *agents_out, float *tasks_out, uint8_t *mask_out,
+                       int64_t *steps_out, void *stream);
+
+/* Terminal results of the last finished episode (worker.py:87,103-108):
+ * out[B,8] f64 = reward(-makespan), n_finished_tasks, success_rate, makespan, time_cost,
+ *                waiting_time, travel_dist, efficiency. Rows of envs not yet done are NaN. */
+int dcm_summary(dcm_env *env, double *out, void *stream);
+
+/* Per-env flags (DCM_FLAG_*), decision counters and current time. Any pointer may be NULL. */
+int dcm_env_status(dcm_env *env, uint32_t *flags_out, int64_t *decisions_out, double *now_out, void *stream);
+
+/* Per-task / per-agent state for parity tests and the per-env facade (any pointer may be NULL):
+ * tasks: finished,feasible u8[B,T]; time_start,time_finish,sum_waiting_time f64[B,T]; status,n_members,n_abandoned i32[B,T]
+ * agents: sum_waiting_time,travel_dist,next_decision,arrival f64[B,A]; x,y f64[B,A]; returned,assigned u8[B,A]; current i32[B,A] (-2 none,-1 depot) */
+int dcm_get_tasks(dcm_env *env, uint8_t *finished, uint8_t *feasible, double *time_start, double *time_finish,
+                  double *sum_wait, int32_t *status, int32_t *n_members, int32_t *n_abandoned, void *stream);
+int dcm_get_agents(dcm_env *env, double *sum_wait, double *travel_dist, double *next_decision, double *arrival,
+                   double *x, double *y, uint8_t *returned, uint8_t *assigned, int32_t *current, void *stream);
+
+/* copy.deepcopy(env) (worker.py:33): snapshot / restore of the mutable SoA state.
+ * dcm_state_bytes gives the buffer size (device memory) needed for all B envs. */
+int dcm_state_bytes(dcm_env *env, size_t *bytes_out);
+int dcm_clone_state(dcm_env *env, void *dst, void *stream);
+int dcm_restore_state(dcm_env *env, const void *src, void *stream);
+
+/* calculate_eulidean_distance (env/task_env.py:161-163) and travel time (:315) on the device, for the
+ * known-answer test of the fp64 sqrt/divide path: dist_out[n], time_out[n] (nullable). */
+int dcm_distance(const double *ax, const double *ay, const double *bx, const double *by, double *dist_out,
+                 double *time_out, int64_t n, void *stream);
+
+/* bytes of canonical state per env: S = 64 + 48*A + 96*T */
+int dcm_record_bytes(dcm_env *env, size_t *bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCMRTA_ENV_H */
