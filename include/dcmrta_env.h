@@ -49,7 +49,7 @@ typedef enum {
 #define DCM_MAX_MEMBERS 5 /* COALITION_SIZE, parameters.py:17: members <= requirement <= 5 */
 #define DCM_FOLLOWER_COLS 4
 
-/* per-env flag bits reported by dcm_env_flags() */
+/* per-env flag bits reported by dcm_env_status */
 #define DCM_FLAG_DONE 1u       /* episode over (terminal box of worker.py:87) */
 #define DCM_FLAG_FINISHED 2u   /* env.finished is True (env/task_env.py:366-373) */
 #define DCM_FLAG_TRUNCATED 4u  /* zero-decider guard fired (the reference would spin) */

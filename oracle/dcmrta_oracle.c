@@ -59,6 +59,7 @@ struct orc_env {
     ivec *route;
     dvec *arrival;
     int *returned, *assigned;
+    double *scr_d; int *scr_i; int32_t *scr_ids; /* scratch, so the hot loop never calls malloc */
     ivec *preset;     /* pre_set_route; consumed from the front via preset_head */
     int *preset_head;
     int *preset_none; /* pre_set_route is None */
@@ -116,6 +117,7 @@ orc_env *orc_create(int A, int T) {
     DA(req, T); DA(status, T); DA(feasible, T); DA(tfin, T); DA(members, T); DA(abandoned, T);
     DA(ax, A); DA(ay, A); DA(nd, A); DA(tdist, A); DA(agent_wait, A); DA(route, A); DA(arrival, A);
     DA(returned, A); DA(assigned, A); DA(preset, A); DA(preset_head, A); DA(preset_none, A);
+    DA(scr_d, 2 * (A + 1)); DA(scr_i, A + 1); DA(scr_ids, A + 1);
 #undef DA
     return e;
 }
@@ -128,6 +130,7 @@ void orc_destroy(orc_env *e) {
     free(e->req); free(e->status); free(e->feasible); free(e->tfin); free(e->members); free(e->abandoned);
     free(e->ax); free(e->ay); free(e->nd); free(e->tdist); free(e->agent_wait); free(e->route); free(e->arrival);
     free(e->returned); free(e->assigned); free(e->preset); free(e->preset_head); free(e->preset_none);
+    free(e->scr_d); free(e->scr_i); free(e->scr_ids);
     free(e);
 }
 void orc_set_params(orc_env *e, double mwt, double max_time) { e->mwt = mwt; e->max_time = max_time; }
@@ -185,8 +188,8 @@ static int all_feasible(orc_env *e, int upto) {
 
 /* env/task_env.py:245-281 */
 void orc_task_update(orc_env *e) {
-    double *arrival = (double *)malloc(sizeof(double) * (e->A + 1));
-    int *drop = (int *)malloc(sizeof(int) * (e->A + 1));
+    double *arrival = e->scr_d;
+    int *drop = e->scr_i;
     for (int t = 0; t < e->T; t++) {
         if (!e->feasible[t]) {                                             /* :249 */
             ivec *mem = &e->members[t];
@@ -230,7 +233,6 @@ void orc_task_update(orc_env *e) {
         int m = e->depot_members.v[i];
         if (e->now >= get_arrival_time(e, m, -1) && allf) e->returned[m] = 1;
     }
-    free(arrival); free(drop);
 }
 
 /* env/task_env.py:207-243 */
@@ -393,10 +395,9 @@ void orc_task_status(orc_env *e, int leader, float *out) {
 
 /* env/task_env.py:366-373 */
 int orc_check_finished(orc_env *e) {
-    int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * e->A);
+    int32_t *ids = e->scr_ids;
     double t;
     int n = orc_next_decision(e, ids, &t), fin = 0;
-    free(ids);
     if (n == 0) {
         e->now = t;                                                         /* :369 */
         fin = 1;
@@ -408,7 +409,7 @@ int orc_check_finished(orc_env *e) {
 
 /* env/task_env.py:344-364 */
 static void calculate_waiting_time(orc_env *e) {
-    double *arrival = (double *)malloc(sizeof(double) * (e->A + 1)), *tmp = (double *)malloc(sizeof(double) * (e->A + 1));
+    double *arrival = e->scr_d, *tmp = e->scr_d + (e->A + 1);
     for (int a = 0; a < e->A; a++) e->agent_wait[a] = 0.0;                  /* :345-346 */
     for (int t = 0; t < e->T; t++) {
         ivec *mem = &e->members[t];
@@ -430,7 +431,6 @@ static void calculate_waiting_time(orc_env *e) {
         }
         for (int j = 0; j < e->abandoned[t].n; j++) e->agent_wait[e->abandoned[t].v[j]] += e->mwt; /* :363-364 */
     }
-    free(arrival); free(tmp);
 }
 
 /* env/task_env.py:420-425 get_episode_reward (reward = -now is read via orc_summary_get) */
@@ -440,7 +440,6 @@ void orc_finish_episode(orc_env *e) {
 }
 
 void orc_summary_get(orc_env *e, orc_summary *s) {
-    double *tmp = (double *)malloc(sizeof(double) * (e->A > e->T ? e->A : e->T));
     int nf = 0;
     for (int t = 0; t < e->T; t++) nf += e->tfin[t];
     s->reward = -e->now;                                                    /* :424 */
@@ -453,7 +452,6 @@ void orc_summary_get(orc_env *e, orc_summary *s) {
     s->metrics[3] = orc_pairwise_sum(e->agent_wait, e->A) / (double)e->A;   /* :106 */
     s->metrics[4] = orc_pairwise_sum(e->tdist, e->A);                       /* :107 */
     s->metrics[5] = orc_pairwise_sum(e->task_wait, e->T) / (double)e->T;    /* :108 */
-    free(tmp);
 }
 
 void orc_final_tasks(orc_env *e, uint8_t *finished, uint8_t *feasible, double *time_start, double *time_finish,

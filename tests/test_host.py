@@ -1,0 +1,69 @@
+"""CPU: host logic and the C-ABI library (load + exported symbols; no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def test_library_exports_every_declared_symbol():
+    from dcmrta_amd import _lib
+    hdr = open(_lib.HEADER_PATH).read()
+    declared = set(re.findall(r"\b(dcm_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.dcm_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product refuses to run instead of silently computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dcmrta_amd import _lib
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    with pytest.raises(_lib.DcmError):
+        BatchedTaskEnv(4, 20, 50, device="cuda:0")
+    with pytest.raises(_lib.DcmError):
+        BatchedTaskEnv(4, 20, 50, device="cpu")
+    lib = _lib.load()
+    p = _lib.DcmParams(4, 20, 50, 0, 10.0, 100.0, 0, 0)
+    h = C.c_void_p()
+    assert lib.dcm_create(C.byref(p), C.byref(h)) == -3
+    assert b"no HIP device" in lib.dcm_last_error()
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dcmrta_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src and "dcmrta_oracle" not in src, f
+
+
+def test_instance_generator_matches_reference_draw_order(golden_dir):
+    """generate_instance == TaskEnv(seed=s) of the reference (arrays stored in the golden traces)."""
+    from dcmrta_amd.instances import generate_batch, generate_instance
+    for p in H.full_traces():
+        tr = H.load_trace(p)
+        g = generate_instance(int(tr["A"]), int(tr["T"]), int(tr["inst_seed"]))
+        for k in ("depot", "task_xy", "req", "dur"):
+            assert np.array_equal(g[k], tr[k]), (p, k)
+    b = generate_batch(3, 20, 50, base_seed=5, first=2)
+    g = generate_instance(20, 50, 8)
+    assert np.array_equal(b["task_xy"][1], g["task_xy"]) and np.array_equal(b["req"][1], g["req"])
+
+
+def test_record_size_formula():
+    """S(A,T) = 64 + 48A + 96T and W = 2S + O + 4 as used by bench.py."""
+    from dcmrta_amd.roofline import algorithmic_bytes_per_step, state_bytes
+    assert state_bytes(20, 50) == 5824 and algorithmic_bytes_per_step(20, 50) == 13203
+    assert algorithmic_bytes_per_step(50, 200) == 48753 and algorithmic_bytes_per_step(100, 500) == 118653
