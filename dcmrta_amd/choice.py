@@ -6,15 +6,20 @@ GPU, so parity is defined on a counter-based protocol instead:
 
     mix64          splitmix64 finaliser
     env_seed(b,e)  = mix64(b + GAMMA*(e+1))              per-env seed from a base seed
-    key(s,d)       = mix64(s + GAMMA*(d+1))              d = running decision counter of the env
-    draw(s,d,slot) = mix64(key(s,d) + GAMMA*(slot+1))    slot 0 leader, 1 action, 2+j follower j
+    key_1(s,d)     = mix64(s + GAMMA*(d+1))              d = running decision counter of the env
+    key_{k+1}      = mix64(key_k + GAMMA)
+    draw(s,d,slot) = 32-bit word `slot` of the stream hi(key_1), lo(key_1), hi(key_2), lo(key_2), ...
+                     slot 0 leader, 1 action, 2+j follower j
+    below(r, n)    = (r * n) >> 32                       multiply-high range reduction (no division)
 
-    leader    = group[draw(s,d,0) % len(group)]          group in ascending agent-id order
-    action    = valid[draw(s,d,1) % len(valid)]          uniform-random policy only
-    followers = k successive rest.pop(draw(s,d,2+j) % len(rest))
+    leader    = group[below(draw(s,d,0), len(group))]    group in ascending agent-id order
+    action    = valid[below(draw(s,d,1), len(valid))]    uniform-random policy only
+    followers = k successive rest.pop(below(draw(s,d,2+j), len(rest)))
 
 Every draw is a pure function of (seed, d, slot): observe() and step() recompute the same
 leader without carrying RNG state, and a policy that ignores slot 1 does not shift the others.
+One 64-bit mix serves leader + action of a decision; a second one is only needed when
+followers are drawn (one wave-uniform computation on the scalar unit of the GPU).
 """
 import numpy as np
 
@@ -34,7 +39,15 @@ def env_seed(base: int, e: int) -> int:
 
 
 def draw(seed_e: int, d: int, slot: int) -> int:
-    return mix64(mix64(seed_e + GAMMA * (d + 1)) + GAMMA * (slot + 1))
+    """32-bit word `slot` of the decision's stream."""
+    key = mix64(seed_e + GAMMA * (d + 1))
+    for _ in range(slot // 2):
+        key = mix64(key + GAMMA)
+    return (key >> 32) if slot % 2 == 0 else (key & 0xFFFFFFFF)
+
+
+def below(r: int, n: int) -> int:
+    return (r * n) >> 32
 
 
 def env_seeds(base: int, first: int, count: int) -> np.ndarray:

@@ -1,16 +1,21 @@
 // dcmrta_env.hip -- MI355X (gfx950) batched coalition-formation + routing environment.
 //
 // One wavefront (64 lanes) per env instance, one env per 64-thread workgroup.  The env's
-// canonical record (S = 64 + 48*A + 96*T bytes, SURVEY.md §8d / DESIGN.md) is copied
+// canonical record (S = 64 + 48*A + 96*T bytes, SURVEY.md §8d / DESIGN.md §3) is copied
 // HBM -> LDS with 16-byte-per-lane coalesced loads, every phase of the reference state
 // machine then runs wave-parallel on the LDS copy (lanes stride over tasks for
 // task_update / mask / task observation and over agents for agent_update / agent
-// observation / next_decision; wave-wide reductions use ballots and cross-lane shuffles),
+// observation / next_decision; wave-wide reductions use ballots and DPP row shifts),
 // and the mutable part of the record is copied back.  The persistent rollout kernel keeps
 // the record in LDS for whole episodes.  All times and positions are fp64 with the
 // reference's operation order (compile with -ffp-contract=off); observations are rounded to
 // fp32 exactly where the reference casts (worker.py:62,64).  No MFMA: the path is
 // elementwise/reduction work, not a dense contraction.
+//
+// The simulator is a template over the batch shape (A agents, T tasks): the BASELINE shapes
+// (20/50, 50/200, 100/500) are compiled with constant LDS offsets and fully unrolled
+// lane-chunk loops, any other shape runs the <0,0> instantiation with runtime sizes.
+// Wave-uniform state (header, choice-protocol keys, group bitmasks) lives in SGPRs.
 //
 // Reference restated: env/task_env.py (TaskEnv) and worker.py:41-112 (the rollout loop).
 // Every device function cites the lines it follows.
@@ -28,11 +33,10 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int M = DCM_MAX_MEMBERS;
-constexpr int AW = (DCM_MAX_AGENTS + 63) / 64;  // 64-bit words of an agent bitmask
+constexpr int AW_MAX = (DCM_MAX_AGENTS + 63) / 64;  // 64-bit words of an agent bitmask
 
 // ---------------------------------------------------------------------------------- record
-// Header of an env record (64 B).
-struct Hdr {
+struct Hdr {  // 64 B header of an env record
     double now;            // current_time, env/task_env.py:28
     uint64_t seed;         // choice-protocol seed of this env
     uint64_t d;            // running decision counter (key of the choice protocol)
@@ -46,85 +50,108 @@ struct Hdr {
 };
 static_assert(sizeof(Hdr) == 64, "header must be 64 bytes");
 
-// ainfo[a]: bit0 returned, bit1 assigned, bit2 in depot['members'], bits 8-15 pending group id,
-//           bits 16-31 number of times the agent was moved to an abandoned_agent list
-constexpr uint32_t A_RETURNED = 1u, A_ASSIGNED = 2u, A_INDEPOT = 4u;
+// ainfo[a]: bit0 returned, bit1 assigned, bit2 in depot['members'], bit3 listed in members of route[-1],
+//           bits 8-15 pending group id, bits 16-31 number of times moved to an abandoned_agent list
+constexpr uint32_t A_RETURNED = 1u, A_ASSIGNED = 2u, A_INDEPOT = 4u, A_MEMBER = 8u, A_GRP = 0xFF00u;
 // tinfo[t]: bits 0-7 requirements, 8-15 status (int8, may be stale: quirk Q3), 16-23 len(members),
 //           bit 24 feasible_assignment, bit 25 finished
 constexpr uint32_t T_FEAS = 1u << 24, T_FIN = 1u << 25;
 
-struct Layout {
-    int32_t A, T;
-    // mutable part
-    uint32_t o_ax, o_ay, o_arr, o_nd, o_tdist;  // f64[A]: location, arrival_time[-1], next_decision, travel_dist
-    uint32_t o_cur, o_ainfo;                    // i32[A] route[-1] (-2 none, -1 depot), u32[A]
-    uint32_t o_ts, o_tf;                        // f64[T] time_start, time_finish
-    uint32_t o_marr;                            // f64[M][T] latest arrival of member slot j of task t
-    uint32_t o_mids;                            // u64[T]   byte j = agent id of member slot j (ordered, Q1)
-    uint32_t o_tinfo, o_tnab;                   // u32[T], u32[T] len(abandoned_agent)
-    uint32_t mut_bytes;                         // 16-aligned size of the mutable part
-    // constant part (instance)
-    uint32_t o_tx, o_ty, o_tdur;                // f64[T] location, time
-    uint32_t rec_bytes;                         // 16-aligned record stride
-    uint32_t lds_bytes;                         // record + scratch (task_wait[T], agent_wait[A])
-    uint32_t o_tw, o_aw;                        // scratch offsets (LDS only)
+__host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+// Record layout as a function of (A,T); see DESIGN.md §3.  All sections 8-byte aligned.
+struct Lay {
+    int A, T;
+    __host__ __device__ constexpr uint32_t ax() const { return 64; }                 // f64[A] location x
+    __host__ __device__ constexpr uint32_t ay() const { return 64 + 8 * A; }         // f64[A] location y
+    __host__ __device__ constexpr uint32_t arr() const { return 64 + 16 * A; }       // f64[A] arrival_time[-1]
+    __host__ __device__ constexpr uint32_t nd() const { return 64 + 24 * A; }        // f64[A] next_decision
+    __host__ __device__ constexpr uint32_t tdist() const { return 64 + 32 * A; }     // f64[A] travel_dist
+    __host__ __device__ constexpr uint32_t cur() const { return 64 + 40 * A; }       // i32[A] route[-1]
+    __host__ __device__ constexpr uint32_t ainfo() const { return 64 + 44 * A; }     // u32[A]
+    __host__ __device__ constexpr uint32_t tb() const { return 64 + 48 * A; }
+    __host__ __device__ constexpr uint32_t ts() const { return tb(); }               // f64[T] time_start
+    __host__ __device__ constexpr uint32_t tf() const { return tb() + 8 * T; }       // f64[T] time_finish
+    __host__ __device__ constexpr uint32_t marr() const { return tb() + 16 * T; }    // f64[M][T] member arrivals
+    __host__ __device__ constexpr uint32_t mids() const { return tb() + 56 * T; }    // u64[T] ordered member ids
+    __host__ __device__ constexpr uint32_t tinfo() const { return tb() + 64 * T; }   // u32[T]
+    __host__ __device__ constexpr uint32_t tnab() const { return tb() + 68 * T; }    // u32[T] len(abandoned_agent)
+    __host__ __device__ constexpr uint32_t mut_bytes() const { return align16(tb() + 72 * T); }
+    __host__ __device__ constexpr uint32_t tx() const { return mut_bytes(); }        // f64[T] task x (instance)
+    __host__ __device__ constexpr uint32_t ty() const { return mut_bytes() + 8 * T; }
+    __host__ __device__ constexpr uint32_t tdur() const { return mut_bytes() + 16 * T; }
+    __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
+    __host__ __device__ constexpr uint32_t tw() const { return rec_bytes(); }        // scratch f64[T] (LDS only)
+    __host__ __device__ constexpr uint32_t aw() const { return rec_bytes() + 8 * T; }  // scratch f64[A]
+    __host__ __device__ constexpr uint32_t lds_bytes() const { return align16(rec_bytes() + 8 * T + 8 * A); }
 };
+static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
 
 struct KP {
     double mwt;       // max_waiting_time
     double max_time;  // MAX_TIME
 };
 
-struct Env {
-    double *ax, *ay, *arr, *nd, *tdist, *ts, *tf, *marr, *tx, *ty, *tdur, *tw, *aw;
-    uint64_t* mids;
-    int32_t* cur;
-    uint32_t *ainfo, *tinfo, *tnab;
-    int A, T;
-};
-
-__device__ __forceinline__ Env make_env(unsigned char* b, const Layout& L) {
-    Env E;
-    E.A = L.A; E.T = L.T;
-    E.ax = (double*)(b + L.o_ax); E.ay = (double*)(b + L.o_ay); E.arr = (double*)(b + L.o_arr);
-    E.nd = (double*)(b + L.o_nd); E.tdist = (double*)(b + L.o_tdist);
-    E.cur = (int32_t*)(b + L.o_cur); E.ainfo = (uint32_t*)(b + L.o_ainfo);
-    E.ts = (double*)(b + L.o_ts); E.tf = (double*)(b + L.o_tf); E.marr = (double*)(b + L.o_marr);
-    E.mids = (uint64_t*)(b + L.o_mids); E.tinfo = (uint32_t*)(b + L.o_tinfo); E.tnab = (uint32_t*)(b + L.o_tnab);
-    E.tx = (double*)(b + L.o_tx); E.ty = (double*)(b + L.o_ty); E.tdur = (double*)(b + L.o_tdur);
-    E.tw = (double*)(b + L.o_tw); E.aw = (double*)(b + L.o_aw);
-    return E;
-}
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 #define WSYNC() __syncthreads() /* 64-thread workgroup: lowers to a wave barrier + LDS wait */
 
+// ---------------------------------------------------------------------------------- uniform helpers
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+__device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((uint64_t)__double_as_longlong(v))); }
+
+__device__ __forceinline__ Hdr load_hdr(const unsigned char* p) {
+    const Hdr* q = (const Hdr*)p;
+    Hdr h;
+    h.now = uni(q->now); h.seed = uni(q->seed); h.d = uni(q->d); h.depot_x = uni(q->depot_x); h.depot_y = uni(q->depot_y);
+    h.flags = uni(q->flags); h.cur_group = uni(q->cur_group); h.n_groups = uni(q->n_groups);
+    h.empty_passes = uni(q->empty_passes); h.ep_steps = uni(q->ep_steps); h.episodes = uni(q->episodes);
+    return h;
+}
+
 // ---------------------------------------------------------------------------------- choice protocol
+// dcmrta_amd/choice.py: stream of 32-bit words hi(key_1), lo(key_1), hi(key_2), ...;
+// slot 0 leader, 1 action, 2+j follower j; below(r,n) = (r*n) >> 32.  All wave-uniform.
 constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ULL;
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ uint64_t draw(uint64_t seed, uint64_t d, uint32_t slot) {
-    return mix64(mix64(seed + GAMMA * (d + 1)) + GAMMA * (uint64_t)(slot + 1));
-}
-// x % n for 1 <= n < 65536 with 32-bit arithmetic only
-__device__ __forceinline__ uint32_t mod_small(uint64_t x, uint32_t n) {
-    uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-    uint32_t c = (0xFFFFFFFFu % n + 1u) % n;  // 2^32 mod n
-    return ((hi % n) * c + (lo % n)) % n;
-}
+__device__ __forceinline__ uint64_t key1(uint64_t seed, uint64_t d) { return mix64(seed + GAMMA * (d + 1)); }
+__device__ __forceinline__ int below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)(uint32_t)n) >> 32); }
 
-// ---------------------------------------------------------------------------------- wave helpers
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o); v = (w < v) ? w : v; }
-    return v;
+// ---------------------------------------------------------------------------------- wave reductions (DPP)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);  // lanes without a source keep their own value
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { double w = __shfl_xor(v, o); v = (w > v) ? w : v; }
-    return v;
+// NaN-ignoring minimum over the wave (np.nanmin), NaN when every lane is NaN.  fmin/fmax are exact.
+__device__ __forceinline__ double wave_nanmin(double v) {
+    v = fmin(v, dpp_f64<0x111, 0xF>(v));  // row_shr:1
+    v = fmin(v, dpp_f64<0x112, 0xF>(v));  // row_shr:2
+    v = fmin(v, dpp_f64<0x114, 0xF>(v));  // row_shr:4
+    v = fmin(v, dpp_f64<0x118, 0xF>(v));  // row_shr:8  -> lane 15 of each row holds the row minimum
+    v = fmin(v, dpp_f64<0x142, 0xA>(v));  // row_bcast:15 into rows 1,3
+    v = fmin(v, dpp_f64<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave minimum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_nanmax(double v) {
+    v = fmax(v, dpp_f64<0x111, 0xF>(v));
+    v = fmax(v, dpp_f64<0x112, 0xF>(v));
+    v = fmax(v, dpp_f64<0x114, 0xF>(v));
+    v = fmax(v, dpp_f64<0x118, 0xF>(v));
+    v = fmax(v, dpp_f64<0x142, 0xA>(v));
+    v = fmax(v, dpp_f64<0x143, 0xC>(v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 // position of the idx-th (0-based) set bit of a wave-uniform mask; all 64 lanes must call
 __device__ __forceinline__ int nth_set_bit(uint64_t m, int idx, int lane) {
@@ -134,43 +161,10 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int idx, int lane) {
     return __ffsll((unsigned long long)sel) - 1;
 }
 
-struct AMask { uint64_t w[AW]; };
-__device__ __forceinline__ int amask_count(const AMask& m) { int n = 0;
-#pragma unroll
-    for (int i = 0; i < AW; i++) n += __popcll(m.w[i]);
-    return n; }
-__device__ __forceinline__ bool amask_test(const AMask& m, int a) { return (m.w[a >> 6] >> (a & 63)) & 1ull; }
-__device__ __forceinline__ void amask_clear(AMask& m, int a) {
-#pragma unroll
-    for (int i = 0; i < AW; i++) if (i == (a >> 6)) m.w[i] &= ~(1ull << (a & 63));
-}
-__device__ __forceinline__ int amask_nth(const AMask& m, int idx, int lane) {
-    int base = 0, res = -1;
-#pragma unroll
-    for (int i = 0; i < AW; i++) {
-        const int c = __popcll(m.w[i]);
-        const int p = nth_set_bit(m.w[i], idx - base, lane);  // -1 when idx-base is out of this word's range
-        if (res < 0 && idx - base >= 0 && idx - base < c) res = i * 64 + p;
-        base += c;
-    }
-    return res;
-}
-// agents whose pending group id equals g
-__device__ __forceinline__ AMask group_mask(const Env& E, int g, int lane) {
-    AMask m;
-#pragma unroll
-    for (int i = 0; i < AW; i++) {
-        const int a = i * 64 + lane;
-        const bool in = (a < E.A) && (int)((E.ainfo[a < E.A ? a : 0] >> 8) & 0xFFu) == g;
-        m.w[i] = __ballot(in);
-    }
-    return m;
-}
-
 // ---------------------------------------------------------------------------------- numpy add.reduce
 // np.sum / np.mean use pairwise summation (8 accumulators per <=128-element block, recursive
 // halving above); restated so the perf metrics of worker.py:103-108 are bit-identical.
-__device__ double psum_block(const double* a, int n) {
+__device__ __noinline__ double psum_block(const double* a, int n) {
     if (n < 8) {
         double r = 0.;
         for (int i = 0; i < n; i++) r += a[i];
@@ -198,7 +192,6 @@ __device__ double psum(const double* a, int n) {
     }
 }
 
-// ---------------------------------------------------------------------------------- primitives
 // env/task_env.py:161-163 -- np.linalg.norm of a 2-vector == sqrt(fma(dy,dy,dx*dx)) on the
 // reference machine (tests/golden/distance_kat.npz).
 __device__ __forceinline__ double dist2(double ax, double ay, double bx, double by) {
@@ -206,495 +199,572 @@ __device__ __forceinline__ double dist2(double ax, double ay, double bx, double 
     return sqrt(__builtin_fma(dy, dy, dx * dx));
 }
 
-// ---------------------------------------------------------------------------------- task_update
-// env/task_env.py:245-281.  Lanes stride over tasks; each lane walks its task's <=M ordered
-// member slots.  The "coalition capability-vs-requirement reduction" is status = req - len(members).
-__device__ void task_update(Env& E, const Hdr& h, const KP& P, int lane) {
-    const double now = h.now, mwt = P.mwt;
-    bool allf = true;
-    for (int t = lane; t < E.T; t += WAVE) {
-        uint32_t info = E.tinfo[t];
-        if (!(info & T_FEAS)) {                                            // :249
+// ================================================================================== the simulator
+template <int CA, int CT>
+struct Sim {
+    static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
+    int rA, rT;
+    unsigned char* base;  // record base (LDS in the env kernels)
+
+    __device__ __forceinline__ int A() const { return CA ? CA : rA; }
+    __device__ __forceinline__ int T() const { return CT ? CT : rT; }
+    __device__ __forceinline__ Lay L() const { return Lay{A(), T()}; }
+    __device__ __forceinline__ double* ax() const { return (double*)(base + L().ax()); }
+    __device__ __forceinline__ double* ay() const { return (double*)(base + L().ay()); }
+    __device__ __forceinline__ double* arr() const { return (double*)(base + L().arr()); }
+    __device__ __forceinline__ double* nd() const { return (double*)(base + L().nd()); }
+    __device__ __forceinline__ double* tdist() const { return (double*)(base + L().tdist()); }
+    __device__ __forceinline__ int32_t* cur() const { return (int32_t*)(base + L().cur()); }
+    __device__ __forceinline__ uint32_t* ainfo() const { return (uint32_t*)(base + L().ainfo()); }
+    __device__ __forceinline__ double* ts() const { return (double*)(base + L().ts()); }
+    __device__ __forceinline__ double* tf() const { return (double*)(base + L().tf()); }
+    __device__ __forceinline__ double* marr() const { return (double*)(base + L().marr()); }
+    __device__ __forceinline__ uint64_t* mids() const { return (uint64_t*)(base + L().mids()); }
+    __device__ __forceinline__ uint32_t* tinfo() const { return (uint32_t*)(base + L().tinfo()); }
+    __device__ __forceinline__ uint32_t* tnab() const { return (uint32_t*)(base + L().tnab()); }
+    __device__ __forceinline__ double* tx() const { return (double*)(base + L().tx()); }
+    __device__ __forceinline__ double* ty() const { return (double*)(base + L().ty()); }
+    __device__ __forceinline__ double* tdur() const { return (double*)(base + L().tdur()); }
+    __device__ __forceinline__ double* tw() const { return (double*)(base + L().tw()); }
+    __device__ __forceinline__ double* aw() const { return (double*)(base + L().aw()); }
+
+    struct AMask { uint64_t w[NAW]; };
+    __device__ __forceinline__ static int am_count(const AMask& m) { int n = 0;
+#pragma unroll
+        for (int i = 0; i < NAW; i++) n += __popcll(m.w[i]);
+        return n; }
+    __device__ __forceinline__ static bool am_test(const AMask& m, int a) {
+        bool r = false;
+#pragma unroll
+        for (int i = 0; i < NAW; i++) if (i == (a >> 6)) r = (m.w[i] >> (a & 63)) & 1ull;
+        return r; }
+    __device__ __forceinline__ static void am_clear(AMask& m, int a) {
+#pragma unroll
+        for (int i = 0; i < NAW; i++) if (i == (a >> 6)) m.w[i] &= ~(1ull << (a & 63)); }
+    __device__ __forceinline__ static void am_set(AMask& m, int a) {
+#pragma unroll
+        for (int i = 0; i < NAW; i++) if (i == (a >> 6)) m.w[i] |= (1ull << (a & 63)); }
+    __device__ __forceinline__ static int am_nth(const AMask& m, int idx, int lane) {
+        if constexpr (NAW == 1) return nth_set_bit(m.w[0], idx, lane);
+        int b = 0, res = -1;
+#pragma unroll
+        for (int i = 0; i < NAW; i++) {
+            const int c = __popcll(m.w[i]);
+            const int p = nth_set_bit(m.w[i], idx - b, lane);
+            if (res < 0 && idx - b >= 0 && idx - b < c) res = i * 64 + p;
+            b += c;
+        }
+        return res; }
+    // agents whose pending group id equals g
+    __device__ __forceinline__ AMask group_mask(int g, int lane) const {
+        AMask m;
+#pragma unroll
+        for (int i = 0; i < NAW; i++) {
+            const int a = i * 64 + lane;
+            const uint32_t ai = ainfo()[a < A() ? a : 0];
+            m.w[i] = __ballot((a < A()) && (int)((ai >> 8) & 0xFFu) == g);
+        }
+        return m; }
+
+    // ------------------------------------------------------------------------------ task_update
+    // env/task_env.py:245-281.  Lanes stride over tasks; each lane holds its task's <=M ordered member
+    // arrivals in registers.  status = requirements - len(members) is the coalition capability-vs-
+    // requirement reduction.  Straight-line predicated code; the member-removal compaction is the only
+    // (rare) divergent branch.
+    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane) const {
+        const double now = h.now, mwt = P.mwt;
+        const int T_ = T();
+        bool allf = true;
+        for (int t = lane; t < T_; t += WAVE) {
+            uint32_t info = tinfo()[t];
+            const bool feas0 = info & T_FEAS;
             const int req = info & 0xFF;
-            const int n = (info >> 16) & 0xFF;                             // :250
-            const uint64_t ids = E.mids[t];
+            const int n = (info >> 16) & 0xFF;                               // :250
             double av[M];
 #pragma unroll
-            for (int j = 0; j < M; j++) av[j] = (j < n) ? E.marr[j * E.T + t] : 0.0;  // :251
-            const int status = req - n;                                    // :252
-            uint32_t keep = 0;                                             // bit j: slot j stays a member
-            bool changed = false;
-            if (status <= 0) {                                             // :254
-                double mx = av[0], mn = av[0];
+            for (int j = 0; j < M; j++) av[j] = marr()[j * T_ + t];          // :251 (slots >= n are ignored below)
+            const double tfin = tf()[t], dur = tdur()[t];
+            const int status = req - n;                                      // :252
+            double mx = -__builtin_inf(), mn = __builtin_inf();
 #pragma unroll
-                for (int j = 1; j < M; j++) if (j < n) { mx = av[j] > mx ? av[j] : mx; mn = av[j] < mn ? av[j] : mn; }
-                if (mx - mn <= mwt) {                                      // :255
-                    E.ts[t] = mx;                                          // :256
-                    E.tf[t] = mx + E.tdur[t];                              // :257
-                    info |= T_FEAS;                                        // :258
-                    keep = (1u << n) - 1u;
+            for (int j = 0; j < M; j++) { const bool v = j < n; mx = (v && av[j] > mx) ? av[j] : mx; mn = (v && av[j] < mn) ? av[j] : mn; }
+            const bool le0 = status <= 0;                                    // :254
+            const bool ok = le0 && (mx - mn <= mwt);                         // :255
+            const double thr = mx - mwt;                                     // :262
+            uint32_t spread = 0, q1 = 0;
+            bool prev = false;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const bool v = j < n;
+                spread |= (uint32_t)(v && av[j] <= thr) << j;                // :262-265
+                // :268-271 iterates task['members'] while removing from it: after a removal the element
+                // that slides into the freed slot is skipped by the list iterator (quirk Q1).
+                const bool e = v && !prev && (now - av[j] >= mwt);           // :269
+                q1 |= (uint32_t)e << j;
+                prev = e;
+            }
+            const uint32_t drop = feas0 ? 0u : (le0 ? (ok ? 0u : spread) : q1);
+            if (!feas0) {
+                if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; }  // :256-258
+                int nn = n;
+                if (drop) {  // rare: compact the surviving members in order
+                    const uint64_t ids = mids()[t];
+                    uint64_t nids = 0;
+                    int k = 0;
+#pragma unroll
+                    for (int j = 0; j < M; j++) if (j < n) {
+                        const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
+                        if (drop & (1u << j)) {
+                            // abandoned_agent.append(member) :265/:271; the agent stops being listed at `t`
+                            atomicAdd(&ainfo()[id], 1u << 16);
+                            if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
+                        } else {
+                            nids |= (uint64_t)id << (8 * k);
+                            marr()[k * T_ + t] = av[j];
+                            k++;
+                        }
+                    }
+                    mids()[t] = nids;
+                    tnab()[t] += (uint32_t)(n - k);
+                    nn = k;
+                }
+                info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
+            } else {
+                info |= (now >= tfin) ? T_FIN : 0u;                          // :273-274
+            }
+            tinfo()[t] = info;
+            allf = allf && (info & T_FEAS);
+        }
+        const bool all_feasible = __all(allf);
+        WSYNC();
+        // depot :277-280
+        const int A_ = A();
+        for (int a = lane; a < A_; a += WAVE) {
+            const uint32_t ai = ainfo()[a];
+            if ((ai & A_INDEPOT) && all_feasible && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+        }
+    }
+
+    // ------------------------------------------------------------------------------ agent_update
+    // env/task_env.py:207-243 (non-reactive branch :226).  `agent in current_task['members']` (:230) is the
+    // cached A_MEMBER bit (set by agent_step, cleared when task_update drops the agent from that task).
+    __device__ __forceinline__ void agent_update(const Hdr& h, const KP& P, int lane) const {
+        const double now = h.now;
+        const int A_ = A();
+        for (int a = lane; a < A_; a += WAVE) {
+            const int c = cur()[a];
+            const int K = c < 0 ? 0 : c;
+            const uint32_t info = tinfo()[K];                                 // :228
+            const double tfK = tf()[K], tsK = ts()[K], av = arr()[a];
+            uint32_t ai = ainfo()[a];
+            const bool member = (info & T_FEAS) && (ai & A_MEMBER);          // :229-230
+            const double ndv = (c == -1) ? __builtin_nan("") : (member ? tfK : av + P.mwt);  // :226,:231,:235,:238
+            const uint32_t as = member ? ((ai & A_ASSIGNED) | ((now >= tsK) ? A_ASSIGNED : 0u)) : 0u;  // :232-240
+            if (c != -2) {                                                   // :209
+                nd()[a] = ndv;
+                if (c >= 0) ainfo()[a] = (ai & ~A_ASSIGNED) | as;            // depot leaves `assigned` untouched (Q6)
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------ terminal
+    // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
+    __device__ void compute_waits(const Hdr& h, const KP& P, int lane) const {
+        const double now = h.now, mwt = P.mwt;
+        const int T_ = T(), A_ = A();
+        for (int t = lane; t < T_; t += WAVE) {
+            const uint32_t info = tinfo()[t];
+            const int n = (info >> 16) & 0xFF;
+            const double ab = (double)tnab()[t] * mwt;
+            double s = 0.;
+            if (n != 0) {                                                    // :349
+                double mx = marr()[t];
+                for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
+                if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - marr()[j * T_ + t]; }   // :351
+                else { for (int j = 0; j < n; j++) s += now - marr()[j * T_ + t]; }               // :354
+            }
+            tw()[t] = s + ab;                                                // :351-357
+        }
+        // :358-364 per agent in task order.  The +max_waiting_time terms of abandoned entries are added as
+        // count*mwt after the member terms (the reference interleaves them in task order): equal to within
+        // a few ulp, see DESIGN.md "documented deviation".
+        for (int a = lane; a < A_; a += WAVE) {
+            double s = 0.;
+            for (int t = 0; t < T_; t++) {
+                const uint32_t info = tinfo()[t];
+                const int n = (info >> 16) & 0xFF;
+                if (n == 0) continue;
+                const uint64_t ids = mids()[t];
+                int pos = -1;
+                for (int j = 0; j < n; j++) if ((int)((ids >> (8 * j)) & 0xFF) == a) pos = j;
+                if (pos < 0) continue;
+                const double mine = marr()[pos * T_ + t];
+                if (info & T_FEAS) {
+                    double mx = marr()[t];
+                    for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
+                    s += mx - mine;                                          // :360
                 } else {
-                    const double thr = mx - mwt;                           // :262
-#pragma unroll
-                    for (int j = 0; j < M; j++) if (j < n) { if (av[j] <= thr) changed = true; else keep |= 1u << j; }
-                }
-            } else {
-                // :268-271 iterates task['members'] while removing from it: after a removal the
-                // element that slides into the freed slot is skipped by the list iterator (Q1).
-                bool skip = false;
-#pragma unroll
-                for (int j = 0; j < M; j++) if (j < n) {
-                    if (skip) { keep |= 1u << j; skip = false; }
-                    else if (now - av[j] >= mwt) { changed = true; skip = true; }   // :269
-                    else keep |= 1u << j;
+                    const double w = now - mine;
+                    s += (w > 0.) ? w : 0.;                                  // :362
                 }
             }
-            int nn = n;
-            if (changed) {
-                uint64_t nids = 0;
-                int k = 0, dropped = 0;
-#pragma unroll
-                for (int j = 0; j < M; j++) if (j < n) {
-                    const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
-                    if (keep & (1u << j)) {
-                        nids |= (uint64_t)id << (8 * k);
-                        E.marr[k * E.T + t] = av[j];
-                        k++;
-                    } else {
-                        atomicAdd(&E.ainfo[id], 1u << 16);                 // :265/:271 abandoned_agent.append(member)
-                        dropped++;
-                    }
-                }
-                E.mids[t] = nids;
-                E.tnab[t] += (uint32_t)dropped;
-                nn = k;
-            }
-            info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
-        } else {
-            if (now >= E.tf[t]) info |= T_FIN;                             // :273-274
+            s += (double)(ainfo()[a] >> 16) * mwt;                           // :363-364
+            aw()[a] = s;
         }
-        E.tinfo[t] = info;
-        allf = allf && (info & T_FEAS);
-    }
-    const bool all_feasible = __all(allf);
-    WSYNC();
-    // depot :277-280
-    for (int a = lane; a < E.A; a += WAVE) {
-        uint32_t ai = E.ainfo[a];
-        if ((ai & A_INDEPOT) && now >= E.arr[a] && all_feasible) E.ainfo[a] = ai | A_RETURNED;
-    }
-}
-
-// ---------------------------------------------------------------------------------- agent_update
-// env/task_env.py:207-243 (non-reactive branch :226)
-__device__ void agent_update(Env& E, const Hdr& h, const KP& P, int lane) {
-    const double now = h.now;
-    for (int a = lane; a < E.A; a += WAVE) {
-        const int c = E.cur[a];
-        if (c == -2) continue;                                             // :209 no arrival yet
-        if (c == -1) { E.nd[a] = __builtin_nan(""); continue; }            // :212,:226
-        const uint32_t info = E.tinfo[c];                                  // :228
-        uint32_t ai = E.ainfo[a];
-        bool member = false;
-        if (info & T_FEAS) {                                               // :229
-            const int n = (info >> 16) & 0xFF;
-            const uint64_t ids = E.mids[c];
-#pragma unroll
-            for (int j = 0; j < M; j++) if (j < n && (int)((ids >> (8 * j)) & 0xFF) == a) member = true;  // :230
-        }
-        if (member) {
-            E.nd[a] = E.tf[c];                                             // :231
-            if (now >= E.ts[c]) ai |= A_ASSIGNED;                          // :232-233
-        } else {
-            E.nd[a] = E.arr[a] + P.mwt;                                    // :235 / :238
-            ai &= ~A_ASSIGNED;                                             // :236 / :240
-        }
-        E.ainfo[a] = ai;
-    }
-}
-
-// ---------------------------------------------------------------------------------- terminal
-// calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
-__device__ void compute_waits(Env& E, const Hdr& h, const KP& P, int lane) {
-    const double now = h.now, mwt = P.mwt;
-    for (int t = lane; t < E.T; t += WAVE) {
-        const uint32_t info = E.tinfo[t];
-        const int n = (info >> 16) & 0xFF;
-        const double ab = (double)E.tnab[t] * mwt;
-        double s = 0.;
-        if (n != 0) {                                                      // :349
-            double mx = E.marr[t];
-            for (int j = 1; j < n; j++) { const double v = E.marr[j * E.T + t]; mx = v > mx ? v : mx; }
-            if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - E.marr[j * E.T + t]; }    // :351
-            else { for (int j = 0; j < n; j++) s += now - E.marr[j * E.T + t]; }                // :354
-        }
-        E.tw[t] = s + ab;                                                  // :351-357
-    }
-    // :358-364, per agent in task order.  The +max_waiting_time terms of abandoned entries are added
-    // as count*mwt after the member terms (the reference interleaves them in task order): equal to
-    // within a few ulp, see DESIGN.md "documented deviations".
-    for (int a = lane; a < E.A; a += WAVE) {
-        double s = 0.;
-        for (int t = 0; t < E.T; t++) {
-            const uint32_t info = E.tinfo[t];
-            const int n = (info >> 16) & 0xFF;
-            if (n == 0) continue;
-            const uint64_t ids = E.mids[t];
-            int pos = -1;
-            for (int j = 0; j < n; j++) if ((int)((ids >> (8 * j)) & 0xFF) == a) pos = j;
-            if (pos < 0) continue;
-            const double mine = E.marr[pos * E.T + t];
-            if (info & T_FEAS) {
-                double mx = E.marr[t];
-                for (int j = 1; j < n; j++) { const double v = E.marr[j * E.T + t]; mx = v > mx ? v : mx; }
-                s += mx - mine;                                            // :360
-            } else {
-                const double w = now - mine;
-                s += (w > 0.) ? w : 0.;                                    // :362
-            }
-        }
-        s += (double)(E.ainfo[a] >> 16) * mwt;                             // :363-364
-        E.aw[a] = s;
-    }
-    WSYNC();
-}
-
-// get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
-__device__ void terminal(Env& E, Hdr& h, const KP& P, int lane, double* __restrict__ row) {
-    WSYNC();
-    compute_waits(E, h, P, lane);
-    int nfin = 0;
-    for (int t0 = 0; t0 < E.T; t0 += WAVE) {
-        const int t = t0 + lane;
-        nfin += __popcll(__ballot(t < E.T && (E.tinfo[t < E.T ? t : 0] & T_FIN)));
-    }
-    // :422 check_finished() once more can only re-assign the same `now`
-    const double T_ = (double)E.T, A_ = (double)E.A;
-    const double m2 = psum<3>(E.ts, E.T) / T_;     // np.nanmean(time_start)      worker.py:105
-    const double m3 = psum<3>(E.aw, E.A) / A_;     // np.mean(agent sum_waiting)  :106
-    const double m4 = psum<3>(E.tdist, E.A);       // np.sum(travel_dist)         :107
-    const double m5 = psum<3>(E.tw, E.T) / T_;     // np.mean(task sum_waiting)   :108
-    if (lane == 0 && row) {
-        row[0] = -h.now;                           // reward, env/task_env.py:424
-        row[1] = (double)nfin;
-        row[2] = (double)nfin / T_;                // success_rate :103
-        row[3] = h.now;                            // makespan :104
-        row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
-    }
-    h.flags |= DCM_FLAG_DONE;
-    h.episodes += 1;
-    h.cur_group = 0;
-}
-
-// ---------------------------------------------------------------------------------- event loop
-// Boxes D + A of SURVEY.md Appendix B: check_finished (worker.py:85, env/task_env.py:366-373), loop
-// test (worker.py:45), next_decision (:283-289), get_unique_group (:291-298), task_update,
-// agent_update (worker.py:50-51).  Returns at the next decision point or after terminal().
-__device__ void advance(Env& E, Hdr& h, const KP& P, int lane, double* __restrict__ row) {
-    const double INF = __builtin_inf();
-    for (;;) {
         WSYNC();
-        // ---- D: check_finished
-        double tmin = INF, maxarr = 0.0;
-        bool allret = true;
-        for (int a = lane; a < E.A; a += WAVE) {
-            const double v = E.nd[a];
-            if (v == v) tmin = v < tmin ? v : tmin;                        // np.nanmin :287
-            const double av = (E.cur[a] != -2) ? E.arr[a] : 0.0;           // max(arrival_time) or 0 :286
-            maxarr = av > maxarr ? av : maxarr;
-            allret = allret && (E.ainfo[a] & A_RETURNED);
+    }
+
+    // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
+    __device__ __noinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+        WSYNC();
+        compute_waits(h, P, lane);
+        const int T_ = T(), A_ = A();
+        int nfin = 0;
+        for (int t0 = 0; t0 < T_; t0 += WAVE) {
+            const int t = t0 + lane;
+            nfin += __popcll(__ballot(t < T_ && (tinfo()[t < T_ ? t : 0] & T_FIN)));
         }
-        tmin = wave_min(tmin);
-        const bool any = tmin < INF;
-        bool finished = false;
-        if (!any) {                                                        // :368
-            h.now = wave_max(maxarr);                                      // :369
-            bool allfin = true;
-            for (int t = lane; t < E.T; t += WAVE) allfin = allfin && (E.tinfo[t] & T_FIN);
-            finished = __all(allret) && __all(allfin);                     // :370
+        // :422 check_finished() once more can only re-assign the same `now`
+        const double Td = (double)T_, Ad = (double)A_;
+        const double m2 = psum<3>(ts(), T_) / Td;      // np.nanmean(time_start)      worker.py:105
+        const double m3 = psum<3>(aw(), A_) / Ad;      // np.mean(agent sum_waiting)  :106
+        const double m4 = psum<3>(tdist(), A_);        // np.sum(travel_dist)         :107
+        const double m5 = psum<3>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
+        if (lane == 0 && row) {
+            row[0] = -h.now;                           // reward, env/task_env.py:424
+            row[1] = (double)nfin;
+            row[2] = (double)nfin / Td;                // success_rate :103
+            row[3] = h.now;                            // makespan :104
+            row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
         }
-        if (finished) h.flags |= DCM_FLAG_FINISHED;
-        if (finished || h.now >= P.max_time) { terminal(E, h, P, lane, row); return; }   // worker.py:45
-        // ---- A: new event
-        h.n_groups = 0;
-        if (any) {
-            h.now = tmin;                                                  // worker.py:49
-            // deciding set: exact equality with the minimum (env/task_env.py:288)
-            bool dec[AW];
-            uint64_t dm[AW];
+        h.flags |= DCM_FLAG_DONE;
+        h.episodes += 1;
+        h.cur_group = 0;
+    }
+
+    // ------------------------------------------------------------------------------ event loop
+    // Boxes D + A of SURVEY.md Appendix B: check_finished (worker.py:85, env/task_env.py:366-373), loop test
+    // (worker.py:45), next_decision (:283-289), get_unique_group (:291-298), task_update, agent_update
+    // (worker.py:50-51).  Returns at the next decision point or after terminal().
+    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+        const int A_ = A(), T_ = T();
+        for (;;) {
+            WSYNC();
+            // ---- D: check_finished.  np.nanmin over next_decision (:287)
+            double ndv[NAW];
+            double lmin = __builtin_nan("");
 #pragma unroll
-            for (int i = 0; i < AW; i++) {
+            for (int i = 0; i < NAW; i++) {
                 const int a = i * 64 + lane;
-                dec[i] = (a < E.A) && (E.nd[a < E.A ? a : 0] == tmin);
-                dm[i] = __ballot(dec[i]);
+                ndv[i] = (a < A_) ? nd()[a] : __builtin_nan("");
+                lmin = fmin(lmin, ndv[i]);
             }
-            // fast path: every deciding agent stands on the same (x,y) -> one group
-            int first = -1;
-#pragma unroll
-            for (int i = AW - 1; i >= 0; i--) if (dm[i]) first = i * 64 + __ffsll((unsigned long long)dm[i]) - 1;
-            const double x0 = E.ax[first], y0 = E.ay[first];
-            bool same = true;
-#pragma unroll
-            for (int i = 0; i < AW; i++) {
-                const int a = i * 64 + lane;
-                if (dec[i]) same = same && (E.ax[a] == x0) && (E.ay[a] == y0);
+            const double tmin = wave_nanmin(lmin);
+            const bool any = (tmin == tmin);
+            bool finished = false;
+            if (!any) {                                                       // :368 nobody can decide any more
+                double maxarr = 0.0;
+                bool allret = true;
+                for (int a = lane; a < A_; a += WAVE) {
+                    const double av = (cur()[a] != -2) ? arr()[a] : 0.0;     // max(arrival_time) or 0 :286
+                    maxarr = av > maxarr ? av : maxarr;
+                    allret = allret && (ainfo()[a] & A_RETURNED);
+                }
+                h.now = wave_nanmax(maxarr);                                  // :369
+                bool allfin = true;
+                for (int t = lane; t < T_; t += WAVE) allfin = allfin && (tinfo()[t] & T_FIN);
+                finished = __all(allret) && __all(allfin);                   // :370
             }
-            if (__all(same)) {
+            if (finished) h.flags |= DCM_FLAG_FINISHED;
+            if (finished || h.now >= P.max_time) { terminal(h, P, lane, row); return; }   // worker.py:45
+            // ---- A: new event
+            h.n_groups = 0;
+            if (any) {
+                h.now = tmin;                                                 // worker.py:49
+                bool dec[NAW];
+                uint64_t dm[NAW];
 #pragma unroll
-                for (int i = 0; i < AW; i++) {
+                for (int i = 0; i < NAW; i++) { dec[i] = (ndv[i] == tmin); dm[i] = __ballot(dec[i]); }  // :288 exact ==
+                int first = -1;
+#pragma unroll
+                for (int i = NAW - 1; i >= 0; i--) if (dm[i]) first = i * 64 + __ffsll((unsigned long long)dm[i]) - 1;
+                // fast path: every deciding agent stands on the same point -> one group
+                const double x0 = ax()[first], y0 = ay()[first];
+                bool same = true;
+                double px[NAW], py[NAW];
+#pragma unroll
+                for (int i = 0; i < NAW; i++) {
                     const int a = i * 64 + lane;
-                    if (a < E.A) E.ainfo[a] = (E.ainfo[a] & ~0xFF00u) | (dec[i] ? (1u << 8) : 0u);
+                    px[i] = ax()[a < A_ ? a : 0]; py[i] = ay()[a < A_ ? a : 0];
+                    same = same && (!dec[i] || (px[i] == x0 && py[i] == y0));
                 }
-                h.n_groups = 1;
-            } else {
-                // general: groups in ascending (x, then y) order == rows of np.unique(axis=0) :293
+                if (__all(same)) {
 #pragma unroll
-                for (int i = 0; i < AW; i++) {
-                    const int a = i * 64 + lane;
-                    if (a < E.A) E.ainfo[a] = (E.ainfo[a] & ~0xFF00u) | (dec[i] ? 0xFF00u : 0u);
+                    for (int i = 0; i < NAW; i++) {
+                        const int a = i * 64 + lane;
+                        if (a < A_) ainfo()[a] = (ainfo()[a] & ~A_GRP) | (dec[i] ? (1u << 8) : 0u);
+                    }
+                    h.n_groups = 1;
+                } else {
+                    // general: groups in ascending (x, then y) order == rows of np.unique(axis=0) :293
+                    bool todo[NAW];
+                    uint32_t gid[NAW];
+#pragma unroll
+                    for (int i = 0; i < NAW; i++) { todo[i] = dec[i]; gid[i] = 0; }
+                    int g = 0;
+                    for (;;) {
+                        double lx = __builtin_nan("");
+#pragma unroll
+                        for (int i = 0; i < NAW; i++) lx = fmin(lx, todo[i] ? px[i] : __builtin_nan(""));
+                        const double mxv = wave_nanmin(lx);
+                        if (!(mxv == mxv)) break;
+                        double ly = __builtin_nan("");
+#pragma unroll
+                        for (int i = 0; i < NAW; i++) ly = fmin(ly, (todo[i] && px[i] == mxv) ? py[i] : __builtin_nan(""));
+                        const double myv = wave_nanmin(ly);
+                        g++;
+#pragma unroll
+                        for (int i = 0; i < NAW; i++) if (todo[i] && px[i] == mxv && py[i] == myv) { gid[i] = (uint32_t)g; todo[i] = false; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NAW; i++) {
+                        const int a = i * 64 + lane;
+                        if (a < A_) ainfo()[a] = (ainfo()[a] & ~A_GRP) | (gid[i] << 8);
+                    }
+                    h.n_groups = g;
                 }
-                int g = 0;
-                for (;;) {
-                    double mx = INF;
+            }
+            WSYNC();
+            task_update(h, P, lane);                                          // worker.py:50
+            WSYNC();
+            agent_update(h, P, lane);                                         // worker.py:51
+            if (!any) {
+                if (++h.empty_passes > 4) { h.flags |= DCM_FLAG_TRUNCATED; terminal(h, P, lane, row); return; }
+                continue;
+            }
+            h.empty_passes = 0;
+            h.cur_group = 1;
+            WSYNC();
+            return;
+        }
+    }
+
+    // reset + clear_decisions (env/task_env.py:116-140); keeps seed, d, episodes
+    __device__ __forceinline__ void reset_state(Hdr& h, int lane) const {
+        for (int t = lane; t < T(); t += WAVE) {
+            const uint32_t req = tinfo()[t] & 0xFF;
+            tinfo()[t] = req | (req << 8);       // status = requirements :131, members [], not feasible/finished
+            tnab()[t] = 0;
+            mids()[t] = 0;
+            ts()[t] = 0.0; tf()[t] = 0.0;
+        }
+        for (int a = lane; a < A(); a += WAVE) {
+            ax()[a] = h.depot_x; ay()[a] = h.depot_y;      // :134
+            arr()[a] = 0.0; nd()[a] = 0.0; tdist()[a] = 0.0;  // :135
+            cur()[a] = -2; ainfo()[a] = 0;
+        }
+        h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0; h.ep_steps = 0;  // :139-140
+    }
+
+    // ------------------------------------------------------------------------------ decisions
+    // worker.py:54 -- the deciding agent of the current group (protocol slot 0), or the injected one
+    __device__ __forceinline__ int pick_leader(Hdr& h, int lane, int leader_in, uint64_t k1, AMask& gm) const {
+        gm = group_mask(h.cur_group, lane);
+        const int glen = am_count(gm);
+        if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }  // unreachable: groups are never empty
+        if (leader_in >= 0) {
+            if (leader_in >= A() || !am_test(gm, leader_in)) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }
+            return leader_in;
+        }
+        return am_nth(gm, below((uint32_t)(k1 >> 32), glen), lane);
+    }
+
+    // worker.py:57-68: mask + both observation tensors relative to `leader`, straight into the policy's input
+    // tensors (fp32 casts of worker.py:62,64).
+    __device__ __forceinline__ void observe(const Hdr& h, int lane, int leader, float* __restrict__ ag,
+                                            float* __restrict__ tk, uint8_t* __restrict__ mask) const {
+        const double now = h.now;
+        const double lx = uni(ax()[leader]), ly = uni(ay()[leader]);
+        const int A_ = A(), T_ = T();
+        // get_current_agent_status, env/task_env.py:165-180
+        if (ag) {
+            for (int a = lane; a < A_; a += WAVE) {
+                const int c = cur()[a];
+                const int K = c < 0 ? 0 : c;
+                const double av = arr()[a], tsK = ts()[K], durK = tdur()[K];
+                const bool on = c >= 0;                                       // :168
+                const double x = av - now, w = now - av, r = tsK + durK - now;
+                const double travel = (on && x > 0.) ? x : 0.;                // :169
+                const double waiting = (on && now <= tsK && w > 0.) ? w : 0.; // :170
+                const double remaining = (on && now >= tsK && r > 0.) ? r : 0.;  // :171
+                float* row = ag + 6 * a;                                      // :176-177
+                row[0] = (float)travel; row[1] = (float)remaining; row[2] = (float)waiting;
+                row[3] = (float)(lx - ax()[a]); row[4] = (float)(ly - ay()[a]);
+                row[5] = (ainfo()[a] & A_ASSIGNED) ? 1.f : 0.f;
+            }
+        }
+        // get_current_task_status :182-190 and get_unfinished_task_mask :192-200
+        bool allmasked = true;
+        for (int t = lane; t < T_; t += WAVE) {
+            const uint32_t info = tinfo()[t];
+            const int status = (int)(int8_t)((info >> 8) & 0xFF);
+            const bool unfinished = !(info & T_FEAS) && status > 0;           // :199
+            allmasked = allmasked && !unfinished;
+            if (mask) mask[t + 1] = unfinished ? 0 : 1;                       // :193
+            if (tk) {
+                float* row = tk + 5 * (t + 1);                                // :185-186
+                row[0] = (float)status; row[1] = (float)(info & 0xFF); row[2] = (float)tdur()[t];
+                row[3] = (float)(tx()[t] - lx); row[4] = (float)(ty()[t] - ly);
+            }
+        }
+        allmasked = __all(allmasked);
+        if (lane == 0) {
+            if (mask) mask[0] = allmasked ? 0 : 1;                            // worker.py:58-61
+            if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = (float)(h.depot_x - lx); tk[4] = (float)(h.depot_y - ly); }  // :188
+        }
+    }
+
+    // uniform-random valid action (protocol slot 1): valid = ascending unmasked action ids
+    __device__ __forceinline__ int pick_random_action(int lane, uint64_t k1) const {
+        const int T_ = T();
+        if constexpr (CT != 0 && CT <= 64) {
+            const uint32_t info = tinfo()[lane < T_ ? lane : 0];
+            const uint64_t bm = __ballot((lane < T_) && !(info & T_FEAS) && ((int)(int8_t)((info >> 8) & 0xFF) > 0));
+            const int nv = __popcll(bm);
+            if (nv == 0) return 0;  // only the depot is unmasked
+            return nth_set_bit(bm, below((uint32_t)k1, nv), lane) + 1;
+        } else {
+            int nv = 0;
+            for (int t0 = 0; t0 < T_; t0 += WAVE) {
+                const int t = t0 + lane;
+                const uint32_t info = tinfo()[t < T_ ? t : 0];
+                nv += __popcll(__ballot((t < T_) && !(info & T_FEAS) && ((int)(int8_t)((info >> 8) & 0xFF) > 0)));
+            }
+            if (nv == 0) return 0;
+            int idx = below((uint32_t)k1, nv);
+            int action = 0;
+            for (int t0 = 0; t0 < T_; t0 += WAVE) {
+                const int t = t0 + lane;
+                const uint32_t info = tinfo()[t < T_ ? t : 0];
+                const uint64_t bm = __ballot((t < T_) && !(info & T_FEAS) && ((int)(int8_t)((info >> 8) & 0xFF) > 0));
+                const int c = __popcll(bm);
+                const int p = nth_set_bit(bm, idx, lane);
+                if (action == 0 && idx >= 0 && idx < c) action = t0 + p + 1;
+                idx -= c;
+            }
+            return action;
+        }
+    }
+
+    // TaskEnv.step (env/task_env.py:326-342) + agent_step (:300-324) for leader + followers, then
+    // task_update / agent_update (worker.py:74-76) and the move to the next decision point.
+    __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
+                                                      int action, uint64_t k1, int nfol_in,
+                                                      const int16_t* __restrict__ fol_in, double* __restrict__ row) const {
+        const int A_ = A(), T_ = T();
+        if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
+        AMask rest = gm0;
+        am_clear(rest, leader);                                               // :328 group.remove(leader)
+        int rlen = am_count(rest);
+        AMask mm;                                                             // members of this step
 #pragma unroll
-                    for (int i = 0; i < AW; i++) {
-                        const int a = i * 64 + lane;
-                        if (a < E.A && (E.ainfo[a] & 0xFF00u) == 0xFF00u) mx = E.ax[a] < mx ? E.ax[a] : mx;
-                    }
-                    mx = wave_min(mx);
-                    if (!(mx < INF)) break;
-                    double my = INF;
+        for (int i = 0; i < NAW; i++) mm.w[i] = 0;
+        am_set(mm, leader);
+        int ml[M];                                                            // ordered: leader, followers
 #pragma unroll
-                    for (int i = 0; i < AW; i++) {
-                        const int a = i * 64 + lane;
-                        if (a < E.A && (E.ainfo[a] & 0xFF00u) == 0xFF00u && E.ax[a] == mx) my = E.ay[a] < my ? E.ay[a] : my;
-                    }
-                    my = wave_min(my);
-                    g++;
+        for (int j = 0; j < M; j++) ml[j] = -1;
+        ml[0] = leader;
+        int nm = 1;
+        double tx_, ty_;
+        if (action == 0) {
+            // vacancy = len(group) (:327): every co-located agent returns with the leader (Q9); the draw
+            // order of the followers cannot change any state, so no draws are spent.
 #pragma unroll
-                    for (int i = 0; i < AW; i++) {
-                        const int a = i * 64 + lane;
-                        if (a < E.A && (E.ainfo[a] & 0xFF00u) == 0xFF00u && E.ax[a] == mx && E.ay[a] == my)
-                            E.ainfo[a] = (E.ainfo[a] & ~0xFF00u) | ((uint32_t)g << 8);
-                    }
+            for (int i = 0; i < NAW; i++) mm.w[i] |= rest.w[i];
+            nm += rlen; rlen = 0;
+            tx_ = h.depot_x; ty_ = h.depot_y;
+        } else {
+            const int k = action - 1;
+            const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
+            int nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
+            if (nfol_in >= 0) nf = nfol_in;
+            if (nf > M - 1 || nf > rlen) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+            uint64_t kk = k1;
+            for (int j = 0; j < nf; j++) {                                    // :331 choice without replacement
+                int f;
+                if (nfol_in >= 0) {
+                    f = fol_in[j];
+                    if (f < 0 || f >= A_ || !am_test(rest, f)) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return; }
+                } else {
+                    if ((j & 1) == 0) kk = mix64(kk + GAMMA);                 // key_{2+j/2}
+                    const uint32_t r = (j & 1) ? (uint32_t)kk : (uint32_t)(kk >> 32);
+                    f = am_nth(rest, below(r, rlen), lane);
                 }
-                h.n_groups = g;
+                am_clear(rest, f); rlen--;                                    // :332-333
+                am_set(mm, f);
+#pragma unroll
+                for (int q = 1; q < M; q++) if (q == nm) ml[q] = f;
+                nm++;
+            }
+            tx_ = uni(tx()[k]); ty_ = uni(ty()[k]);
+        }
+        // agent_step for every member (:300-324); independent per agent
+#pragma unroll
+        for (int i = 0; i < NAW; i++) {
+            const int a = i * 64 + lane;
+            if (a < A_ && ((mm.w[i] >> lane) & 1ull)) {
+                const double d = dist2(ax()[a], ay()[a], tx_, ty_);
+                const double travel_time = d / 0.2;                           // :315 velocity 0.2 (:99)
+                tdist()[a] += d;                                              // :317
+                arr()[a] = h.now + travel_time;                               // :318
+                ax()[a] = tx_; ay()[a] = ty_;                                 // :320
+                cur()[a] = action - 1;                                        // :314 route.append
+                uint32_t ai = ainfo()[a] & ~(A_GRP | A_MEMBER);               // leaves the pending group
+                ai |= (action == 0) ? A_INDEPOT : A_MEMBER;                   // :321-322 listed in the target's members
+                ainfo()[a] = ai;
             }
         }
         WSYNC();
-        task_update(E, h, P, lane);                                        // worker.py:50
+        if (action > 0) {
+            // :321-322 members.append unless already listed; a re-joining agent keeps its slot but
+            // get_arrival_time (:202-205) now returns the new, later arrival (Q4)
+            const int k = action - 1;
+            const uint32_t info = uni(tinfo()[k]);
+            uint64_t ids = uni(mids()[k]);
+            int n = (info >> 16) & 0xFF;
+            bool ovf = false;
+#pragma unroll
+            for (int j = 0; j < M; j++) if (j < nm) {
+                const int m = ml[j];
+                int pos = -1;
+#pragma unroll
+                for (int q = 0; q < M; q++) if (q < n && (int)((ids >> (8 * q)) & 0xFF) == m) pos = q;
+                if (pos < 0) {
+                    if (n >= M) { ovf = true; }
+                    else { pos = n++; ids = (ids & ~(0xFFull << (8 * pos))) | ((uint64_t)m << (8 * pos)); }
+                }
+                if (pos >= 0 && lane == 0) marr()[pos * T_ + k] = arr()[m];
+            }
+            if (ovf) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+            if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
+        }
+        h.d += 1; h.ep_steps += 1;
         WSYNC();
-        agent_update(E, h, P, lane);                                       // worker.py:51
-        if (!any) {
-            if (++h.empty_passes > 4) { h.flags |= DCM_FLAG_TRUNCATED; terminal(E, h, P, lane, row); return; }
-            continue;
-        }
-        h.empty_passes = 0;
-        h.cur_group = 1;
+        task_update(h, P, lane);                                              // worker.py:74
         WSYNC();
-        return;
+        agent_update(h, P, lane);                                             // worker.py:76
+        WSYNC();
+        if (rlen > 0) return;                                                 // worker.py:53 same group, next leader
+        if (h.cur_group < h.n_groups) { h.cur_group++; return; }              // worker.py:52 next group
+        advance(h, P, lane, row);                                             // worker.py:85 -> :45
     }
-}
 
-// reset + clear_decisions (env/task_env.py:116-140); keeps seed, d, episodes
-__device__ void reset_state(Env& E, Hdr& h, int lane) {
-    for (int t = lane; t < E.T; t += WAVE) {
-        const uint32_t req = E.tinfo[t] & 0xFF;
-        E.tinfo[t] = req | (req << 8);       // status = requirements :131, members [] , not feasible/finished
-        E.tnab[t] = 0;
-        E.mids[t] = 0;
-        E.ts[t] = 0.0; E.tf[t] = 0.0;
+    __device__ __forceinline__ void write_inactive_obs(int lane, float* ag, float* tk, uint8_t* mask) const {
+        if (ag) for (int i = lane; i < 6 * A(); i += WAVE) ag[i] = 0.f;
+        if (tk) for (int i = lane; i < 5 * (T() + 1); i += WAVE) tk[i] = 0.f;
+        if (mask) for (int i = lane; i <= T(); i += WAVE) mask[i] = (i == 0) ? 0 : 1;
     }
-    for (int a = lane; a < E.A; a += WAVE) {
-        E.ax[a] = h.depot_x; E.ay[a] = h.depot_y;  // :134
-        E.arr[a] = 0.0; E.nd[a] = 0.0; E.tdist[a] = 0.0;  // :135
-        E.cur[a] = -2; E.ainfo[a] = 0;
-    }
-    h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0; h.ep_steps = 0;  // :139-140
-}
-
-// ---------------------------------------------------------------------------------- decisions
-// worker.py:54 -- the deciding agent of the current group (protocol slot 0), or the injected one
-__device__ int pick_leader(const Env& E, Hdr& h, int lane, int leader_in, AMask& gm) {
-    gm = group_mask(E, h.cur_group, lane);
-    const int glen = amask_count(gm);
-    if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }  // unreachable: groups are never empty
-    if (leader_in >= 0) {
-        if (leader_in >= E.A || !amask_test(gm, leader_in)) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }
-        return leader_in;
-    }
-    const int idx = (int)mod_small(draw(h.seed, h.d, 0), (uint32_t)glen);
-    return amask_nth(gm, idx, lane);
-}
-
-// worker.py:57-68: mask + both observation tensors relative to `leader`, straight into the policy's
-// input tensors (fp32 casts of worker.py:62,64).  Returns true when every task is masked.
-__device__ bool observe(const Env& E, const Hdr& h, int lane, int leader, float* __restrict__ ag,
-                        float* __restrict__ tk, uint8_t* __restrict__ mask) {
-    const double now = h.now;
-    const double lx = E.ax[leader], ly = E.ay[leader];
-    // get_current_agent_status, env/task_env.py:165-180
-    if (ag) {
-        for (int a = lane; a < E.A; a += WAVE) {
-            double travel = 0., waiting = 0., remaining = 0.;
-            const int c = E.cur[a];
-            if (c >= 0) {                                                  // :168
-                const double av = E.arr[a], tsK = E.ts[c];
-                const double x = av - now; travel = x > 0. ? x : 0.;       // :169
-                if (now <= tsK) { const double w = now - av; waiting = w > 0. ? w : 0.; }               // :170
-                if (now >= tsK) { const double r = tsK + E.tdur[c] - now; remaining = r > 0. ? r : 0.; } // :171
-            }
-            float* row = ag + 6 * a;                                       // :176-177
-            row[0] = (float)travel; row[1] = (float)remaining; row[2] = (float)waiting;
-            row[3] = (float)(lx - E.ax[a]); row[4] = (float)(ly - E.ay[a]);
-            row[5] = (E.ainfo[a] & A_ASSIGNED) ? 1.f : 0.f;
-        }
-    }
-    // get_current_task_status :182-190 and get_unfinished_task_mask :192-200
-    bool allmasked = true;
-    for (int t = lane; t < E.T; t += WAVE) {
-        const uint32_t info = E.tinfo[t];
-        const int status = (int)(int8_t)((info >> 8) & 0xFF);
-        const bool unfinished = !(info & T_FEAS) && status > 0;            // :199
-        allmasked = allmasked && !unfinished;
-        if (mask) mask[t + 1] = unfinished ? 0 : 1;                        // :193
-        if (tk) {
-            float* row = tk + 5 * (t + 1);                                 // :185-186
-            row[0] = (float)status; row[1] = (float)(info & 0xFF); row[2] = (float)E.tdur[t];
-            row[3] = (float)(E.tx[t] - lx); row[4] = (float)(E.ty[t] - ly);
-        }
-    }
-    allmasked = __all(allmasked);
-    if (lane == 0) {
-        if (mask) mask[0] = allmasked ? 0 : 1;                             // worker.py:58-61
-        if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = (float)(h.depot_x - lx); tk[4] = (float)(h.depot_y - ly); }  // :188
-    }
-    return allmasked;
-}
-
-// uniform-random valid action (protocol slot 1): valid = ascending unmasked action ids
-__device__ int pick_random_action(const Env& E, const Hdr& h, int lane) {
-    int nv = 0;
-    for (int t0 = 0; t0 < E.T; t0 += WAVE) {
-        const int t = t0 + lane;
-        const uint32_t info = E.tinfo[t < E.T ? t : 0];
-        const bool un = (t < E.T) && !(info & T_FEAS) && ((int)(int8_t)((info >> 8) & 0xFF) > 0);
-        nv += __popcll(__ballot(un));
-    }
-    if (nv == 0) return 0;  // only the depot is unmasked
-    int idx = (int)mod_small(draw(h.seed, h.d, 1), (uint32_t)nv);
-    int action = 0;
-    for (int t0 = 0; t0 < E.T; t0 += WAVE) {
-        const int t = t0 + lane;
-        const uint32_t info = E.tinfo[t < E.T ? t : 0];
-        const bool un = (t < E.T) && !(info & T_FEAS) && ((int)(int8_t)((info >> 8) & 0xFF) > 0);
-        const uint64_t bm = __ballot(un);
-        const int c = __popcll(bm);
-        const int p = nth_set_bit(bm, idx, lane);
-        if (action == 0 && idx >= 0 && idx < c) action = t0 + p + 1;
-        idx -= c;
-    }
-    return action;
-}
-
-// TaskEnv.step (env/task_env.py:326-342) + agent_step (:300-324) for leader + followers, then
-// task_update / agent_update (worker.py:74-76) and the move to the next decision point.
-__device__ void apply_and_advance(Env& E, Hdr& h, const KP& P, int lane, int leader, const AMask& gm0, int action,
-                                  int nfol_in, const int16_t* __restrict__ fol_in, double* __restrict__ row) {
-    if (action < 0 || action > E.T) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
-    AMask rest = gm0;
-    amask_clear(rest, leader);                                             // :328 group.remove(leader)
-    int rlen = amask_count(rest);
-    AMask mm;                                                              // members of this step
-#pragma unroll
-    for (int i = 0; i < AW; i++) mm.w[i] = 0;
-    mm.w[leader >> 6] |= 1ull << (leader & 63);
-    int ml[M];                                                             // ordered: leader, followers
-#pragma unroll
-    for (int j = 0; j < M; j++) ml[j] = -1;
-    ml[0] = leader;
-    int nm = 1;
-    double tx_, ty_;
-    if (action == 0) {
-        // vacancy = len(group) (:327): every co-located agent returns with the leader (Q9);
-        // the draw order of the followers does not change any state, so no draws are spent.
-#pragma unroll
-        for (int i = 0; i < AW; i++) mm.w[i] |= rest.w[i];
-        nm += rlen; rlen = 0;
-        tx_ = h.depot_x; ty_ = h.depot_y;
-    } else {
-        const int k = action - 1;
-        const int vacancy = (int)(int8_t)((E.tinfo[k] >> 8) & 0xFF);       // :327 task status (may be stale)
-        int nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
-        if (nfol_in >= 0) nf = nfol_in;
-        if (nf > M - 1 || nf > rlen) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
-        for (int j = 0; j < nf; j++) {                                     // :331 choice without replacement
-            int f;
-            if (nfol_in >= 0) {
-                f = fol_in[j];
-                if (f < 0 || f >= E.A || !amask_test(rest, f)) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return; }
-            } else {
-                f = amask_nth(rest, (int)mod_small(draw(h.seed, h.d, 2 + j), (uint32_t)rlen), lane);
-            }
-            amask_clear(rest, f); rlen--;                                  // :332-333
-#pragma unroll
-            for (int i = 0; i < AW; i++) if (i == (f >> 6)) mm.w[i] |= 1ull << (f & 63);
-#pragma unroll
-            for (int q = 1; q < M; q++) if (q == nm) ml[q] = f;
-            nm++;
-        }
-        tx_ = E.tx[k]; ty_ = E.ty[k];
-    }
-    // agent_step for every member (:300-324); independent per agent
-#pragma unroll
-    for (int i = 0; i < AW; i++) {
-        const int a = i * 64 + lane;
-        if (a < E.A && ((mm.w[i] >> lane) & 1ull)) {
-            const double d = dist2(E.ax[a], E.ay[a], tx_, ty_);
-            const double travel_time = d / 0.2;                            // :315 velocity 0.2 (:99)
-            E.tdist[a] += d;                                               // :317
-            E.arr[a] = h.now + travel_time;                                // :318
-            E.ax[a] = tx_; E.ay[a] = ty_;                                  // :320
-            E.cur[a] = action - 1;                                         // :314 route.append
-            uint32_t ai = E.ainfo[a] & ~0xFF00u;                           // leaves the pending group
-            if (action == 0) ai |= A_INDEPOT;                              // :321-322 depot['members']
-            E.ainfo[a] = ai;
-        }
-    }
-    WSYNC();
-    if (action > 0) {
-        // :321-322 members.append unless already listed; a re-joining agent keeps its slot but
-        // get_arrival_time (:202-205) now returns the new, later arrival (Q4)
-        const int k = action - 1;
-        uint32_t info = E.tinfo[k];
-        uint64_t ids = E.mids[k];
-        int n = (info >> 16) & 0xFF;
-        bool ovf = false;
-#pragma unroll
-        for (int j = 0; j < M; j++) if (j < nm) {
-            const int m = ml[j];
-            int pos = -1;
-#pragma unroll
-            for (int q = 0; q < M; q++) if (q < n && (int)((ids >> (8 * q)) & 0xFF) == m) pos = q;
-            if (pos < 0) {
-                if (n >= M) { ovf = true; }
-                else { pos = n++; ids = (ids & ~(0xFFull << (8 * pos))) | ((uint64_t)m << (8 * pos)); }
-            }
-            if (pos >= 0 && lane == 0) E.marr[pos * E.T + k] = E.arr[m];
-        }
-        if (ovf) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
-        if (lane == 0) { E.mids[k] = ids; E.tinfo[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
-    }
-    h.d += 1; h.ep_steps += 1;
-    WSYNC();
-    task_update(E, h, P, lane);                                            // worker.py:74
-    WSYNC();
-    agent_update(E, h, P, lane);                                           // worker.py:76
-    WSYNC();
-    if (rlen > 0) return;                                                  // worker.py:53 same group, next leader
-    if (h.cur_group < h.n_groups) { h.cur_group++; return; }               // worker.py:52 next group
-    advance(E, h, P, lane, row);                                           // worker.py:85 -> :45
-}
+};
 
 // ---------------------------------------------------------------------------------- record I/O
 __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
@@ -702,20 +772,23 @@ __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* 
     uint4* d = (uint4*)dst;
     for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = s[i];
 }
-
-extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
+    if (lane == 0) *(Hdr*)smem = h;
+}
 
 // ---------------------------------------------------------------------------------- kernels
-__global__ __launch_bounds__(WAVE) void k_load_instances(Layout L, unsigned char* state, const double* depot,
+__global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned char* state, const double* depot,
                                                         const double* task_xy, const int32_t* req, const double* dur) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    unsigned char* rec = state + (size_t)e * L.rec_bytes;
-    Env E = make_env(rec, L);
-    for (int t = lane; t < L.T; t += WAVE) {
-        E.tx[t] = task_xy[((size_t)e * L.T + t) * 2];
-        E.ty[t] = task_xy[((size_t)e * L.T + t) * 2 + 1];
-        E.tdur[t] = dur[(size_t)e * L.T + t];
-        E.tinfo[t] = (uint32_t)req[(size_t)e * L.T + t] & 0xFF;
+    const Lay L{A, T};
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    double *tx = (double*)(rec + L.tx()), *ty = (double*)(rec + L.ty()), *td = (double*)(rec + L.tdur());
+    uint32_t* ti = (uint32_t*)(rec + L.tinfo());
+    for (int t = lane; t < T; t += WAVE) {
+        tx[t] = task_xy[((size_t)e * T + t) * 2];
+        ty[t] = task_xy[((size_t)e * T + t) * 2 + 1];
+        td[t] = dur[(size_t)e * T + t];
+        ti[t] = (uint32_t)req[(size_t)e * T + t] & 0xFF;
     }
     if (lane == 0) {
         Hdr* h = (Hdr*)rec;
@@ -724,74 +797,77 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(Layout L, unsigned char
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_reset(Layout L, KP P, unsigned char* state, const uint64_t* seeds,
+template <int CA, int CT>
+__global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned char* state, const uint64_t* seeds,
                                                double* summary) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    unsigned char* rec = state + (size_t)e * L.rec_bytes;
-    copy16(smem, rec, L.rec_bytes, lane);
+    Sim<CA, CT> S{A, T, smem};
+    const Lay L = S.L();
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    copy16(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
+    Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0; h.episodes = 0;
-    reset_state(E, h, lane);
+    S.reset_state(h, lane);
     if (lane < 8) summary[(size_t)e * 8 + lane] = __builtin_nan("");
-    advance(E, h, P, lane, summary + (size_t)e * 8);
+    S.advance(h, P, lane, summary + (size_t)e * 8);
     WSYNC();
-    if (lane == 0) *(Hdr*)smem = h;
+    store_hdr(h, lane);
     WSYNC();
-    copy16(rec, smem, L.mut_bytes, lane);
+    copy16(rec, smem, L.mut_bytes(), lane);
 }
 
-__device__ void write_inactive_obs(const Env& E, int lane, float* ag, float* tk, uint8_t* mask) {
-    if (ag) for (int i = lane; i < 6 * E.A; i += WAVE) ag[i] = 0.f;
-    if (tk) for (int i = lane; i < 5 * (E.T + 1); i += WAVE) tk[i] = 0.f;
-    if (mask) for (int i = lane; i <= E.T; i += WAVE) mask[i] = (i == 0) ? 0 : 1;
-}
-
-__global__ __launch_bounds__(WAVE) void k_observe(Layout L, unsigned char* state, float* agents_out, float* tasks_out,
+template <int CA, int CT>
+__global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
                                                  const int32_t* leader_in) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    unsigned char* rec = state + (size_t)e * L.rec_bytes;
-    copy16(smem, rec, L.rec_bytes, lane);
+    Sim<CA, CT> S{A, T, smem};
+    const Lay L = S.L();
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    copy16(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
+    Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
     float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
     int leader = -1;
+    const uint32_t flags0 = h.flags;
     if (!(h.flags & DCM_FLAG_DONE)) {
-        AMask gm;
-        leader = pick_leader(E, h, lane, leader_in ? leader_in[e] : -1, gm);
+        typename Sim<CA, CT>::AMask gm;
+        leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm);
     }
-    if (leader >= 0) observe(E, h, lane, leader, ag, tk, mk);
-    else write_inactive_obs(E, lane, ag, tk, mk);
+    if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
+    else S.write_inactive_obs(lane, ag, tk, mk);
     if (lane == 0) {
         if (leader_out) leader_out[e] = leader;
         if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
-        if (leader < 0 && !(((Hdr*)rec)->flags & DCM_FLAG_DONE)) ((Hdr*)rec)->flags = h.flags;  // injected-leader error
+        if (h.flags != flags0) ((Hdr*)rec)->flags = h.flags;  // injected-leader error freezes the env
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_step(Layout L, KP P, unsigned char* state, const int32_t* actions,
+template <int CA, int CT>
+__global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char* state, const int32_t* actions,
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    unsigned char* rec = state + (size_t)e * L.rec_bytes;
-    copy16(smem, rec, L.rec_bytes, lane);
+    Sim<CA, CT> S{A, T, smem};
+    using AMask = typename Sim<CA, CT>::AMask;
+    const Lay L = S.L();
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    copy16(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
+    Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
     if (was_active) {
         AMask gm;
-        const int leader = pick_leader(E, h, lane, leader_in ? leader_in[e] : -1, gm);
+        const uint64_t k1 = key1(h.seed, h.d);
+        const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm);
         if (leader >= 0) {
             const int nf = nfol_in ? nfol_in[e] : -1;
-            apply_and_advance(E, h, P, lane, leader, gm, actions[e], nf, fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr,
-                              summary + (size_t)e * 8);
+            S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
+                                fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -801,9 +877,9 @@ __global__ __launch_bounds__(WAVE) void k_step(Layout L, KP P, unsigned char* st
         float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
         uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
         int leader = -1;
-        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = pick_leader(E, h, lane, -1, gm); }
-        if (leader >= 0) observe(E, h, lane, leader, ag, tk, mk);
-        else write_inactive_obs(E, lane, ag, tk, mk);
+        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm); }
+        if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
+        else S.write_inactive_obs(lane, ag, tk, mk);
         if (lane == 0) {
             if (leader_out) leader_out[e] = leader;
             if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
@@ -811,22 +887,25 @@ __global__ __launch_bounds__(WAVE) void k_step(Layout L, KP P, unsigned char* st
     }
     if (was_active) {
         WSYNC();
-        if (lane == 0) *(Hdr*)smem = h;
+        store_hdr(h, lane);
         WSYNC();
-        copy16(rec, smem, L.mut_bytes, lane);
+        copy16(rec, smem, L.mut_bytes(), lane);
     }
 }
 
 // Config-2 hot path: whole episodes in one persistent launch, record resident in LDS.
-__global__ __launch_bounds__(WAVE) void k_rollout_random(Layout L, KP P, unsigned char* state, int episodes,
+template <int CA, int CT>
+__global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    unsigned char* rec = state + (size_t)e * L.rec_bytes;
-    copy16(smem, rec, L.rec_bytes, lane);
+    Sim<CA, CT> S{A, T, smem};
+    using AMask = typename Sim<CA, CT>::AMask;
+    const Lay L = S.L();
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    copy16(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
+    Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
     float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
@@ -834,84 +913,86 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(Layout L, KP P, unsigne
     int64_t steps = 0;
     for (int ep = 0; ep < episodes; ep++) {
         if (h.flags & DCM_FLAG_DONE) {  // restart from the loaded instance; d keeps running
-            const uint32_t err = h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER);
-            if (err) break;
-            reset_state(E, h, lane);
-            advance(E, h, P, lane, row);
+            if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) break;
+            S.reset_state(h, lane);
+            S.advance(h, P, lane, row);
         }
         while (!(h.flags & DCM_FLAG_DONE)) {
             AMask gm;
-            const int leader = pick_leader(E, h, lane, -1, gm);
-            if (leader < 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; break; }
-            observe(E, h, lane, leader, ag, tk, mk);
-            const int action = pick_random_action(E, h, lane);
-            apply_and_advance(E, h, P, lane, leader, gm, action, -1, nullptr, row);
+            const uint64_t k1 = key1(h.seed, h.d);
+            const int leader = S.pick_leader(h, lane, -1, k1, gm);
+            if (leader < 0) break;
+            S.observe(h, lane, leader, ag, tk, mk);
+            const int action = S.pick_random_action(lane, k1);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row);
             steps++;
         }
     }
     if (lane == 0 && steps_out) steps_out[e] = steps;
     WSYNC();
-    if (lane == 0) *(Hdr*)smem = h;
+    store_hdr(h, lane);
     WSYNC();
-    copy16(rec, smem, L.mut_bytes, lane);
+    copy16(rec, smem, L.mut_bytes(), lane);
 }
 
-__global__ __launch_bounds__(WAVE) void k_env_status(Layout L, const unsigned char* state, int B, uint32_t* flags_out,
+__global__ __launch_bounds__(WAVE) void k_env_status(int A, int T, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out) {
     const int e = blockIdx.x * WAVE + threadIdx.x;
     if (e >= B) return;
-    const Hdr* h = (const Hdr*)(state + (size_t)e * L.rec_bytes);
+    const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{A, T}.rec_bytes());
     if (flags_out) flags_out[e] = h->flags;
     if (dec_out) dec_out[e] = (int64_t)h->d;
     if (now_out) now_out[e] = h->now;
 }
 
-__global__ __launch_bounds__(WAVE) void k_get_tasks(Layout L, KP P, unsigned char* state, uint8_t* finished,
+__global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
                                                    int32_t* n_abandoned) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    copy16(smem, state + (size_t)e * L.rec_bytes, L.rec_bytes, lane);
+    Sim<0, 0> S{A, T, smem};
+    const Lay L = S.L();
+    copy16(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
-    if (sum_wait) compute_waits(E, h, P, lane);
-    for (int t = lane; t < L.T; t += WAVE) {
-        const size_t o = (size_t)e * L.T + t;
-        const uint32_t info = E.tinfo[t];
+    Hdr h = load_hdr(smem);
+    if (sum_wait) S.compute_waits(h, P, lane);
+    for (int t = lane; t < T; t += WAVE) {
+        const size_t o = (size_t)e * T + t;
+        const uint32_t info = S.tinfo()[t];
         if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
         if (feasible) feasible[o] = (info & T_FEAS) ? 1 : 0;
-        if (time_start) time_start[o] = E.ts[t];
-        if (time_finish) time_finish[o] = E.tf[t];
-        if (sum_wait) sum_wait[o] = E.tw[t];
+        if (time_start) time_start[o] = S.ts()[t];
+        if (time_finish) time_finish[o] = S.tf()[t];
+        if (sum_wait) sum_wait[o] = S.tw()[t];
         if (status) status[o] = (int)(int8_t)((info >> 8) & 0xFF);
         if (n_members) n_members[o] = (info >> 16) & 0xFF;
-        if (n_abandoned) n_abandoned[o] = (int32_t)E.tnab[t];
+        if (n_abandoned) n_abandoned[o] = (int32_t)S.tnab()[t];
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_get_agents(Layout L, KP P, unsigned char* state, double* sum_wait,
+__global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
                                                     int32_t* current) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    copy16(smem, state + (size_t)e * L.rec_bytes, L.rec_bytes, lane);
+    Sim<0, 0> S{A, T, smem};
+    const Lay L = S.L();
+    copy16(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     WSYNC();
-    Env E = make_env(smem, L);
-    Hdr h = *(Hdr*)smem;
-    if (sum_wait) compute_waits(E, h, P, lane);
-    for (int a = lane; a < L.A; a += WAVE) {
-        const size_t o = (size_t)e * L.A + a;
-        const uint32_t ai = E.ainfo[a];
-        if (sum_wait) sum_wait[o] = E.aw[a];
-        if (travel_dist) travel_dist[o] = E.tdist[a];
-        if (next_decision) next_decision[o] = E.nd[a];
-        if (arrival) arrival[o] = E.arr[a];
-        if (x) x[o] = E.ax[a];
-        if (y) y[o] = E.ay[a];
+    Hdr h = load_hdr(smem);
+    if (sum_wait) S.compute_waits(h, P, lane);
+    for (int a = lane; a < A; a += WAVE) {
+        const size_t o = (size_t)e * A + a;
+        const uint32_t ai = S.ainfo()[a];
+        if (sum_wait) sum_wait[o] = S.aw()[a];
+        if (travel_dist) travel_dist[o] = S.tdist()[a];
+        if (next_decision) next_decision[o] = S.nd()[a];
+        if (arrival) arrival[o] = S.arr()[a];
+        if (x) x[o] = S.ax()[a];
+        if (y) y[o] = S.ay()[a];
         if (returned) returned[o] = (ai & A_RETURNED) ? 1 : 0;
         if (assigned) assigned[o] = (ai & A_ASSIGNED) ? 1 : 0;
-        if (current) current[o] = E.cur[a];
+        if (current) current[o] = S.cur()[a];
     }
 }
 
@@ -936,34 +1017,20 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
         if (_e != hipSuccess) return fail(DCM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-uint32_t align_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
-
-Layout make_layout(int A, int T) {
-    Layout L{};
-    L.A = A; L.T = T;
-    uint32_t o = sizeof(Hdr);
-    L.o_ax = o; o += 8 * A; L.o_ay = o; o += 8 * A; L.o_arr = o; o += 8 * A; L.o_nd = o; o += 8 * A; L.o_tdist = o; o += 8 * A;
-    L.o_cur = o; o += 4 * A; L.o_ainfo = o; o += 4 * A;
-    o = align_up(o, 8);
-    L.o_ts = o; o += 8 * T; L.o_tf = o; o += 8 * T;
-    L.o_marr = o; o += 8 * M * T;
-    L.o_mids = o; o += 8 * T;
-    L.o_tinfo = o; o += 4 * T; L.o_tnab = o; o += 4 * T;
-    L.mut_bytes = align_up(o, 16);
-    o = L.mut_bytes;
-    L.o_tx = o; o += 8 * T; L.o_ty = o; o += 8 * T; L.o_tdur = o; o += 8 * T;
-    L.rec_bytes = align_up(o, 16);
-    o = L.rec_bytes;
-    L.o_tw = o; o += 8 * T; L.o_aw = o; o += 8 * A;
-    L.lds_bytes = align_up(o, 16);
-    return L;
-}
+// shape dispatch: BASELINE shapes get the constant-offset instantiation
+#define DISPATCH_SHAPE(A, T, CALL)                                       \
+    do {                                                                 \
+        if ((A) == 20 && (T) == 50) { CALL(20, 50); }                    \
+        else if ((A) == 50 && (T) == 200) { CALL(50, 200); }             \
+        else if ((A) == 100 && (T) == 500) { CALL(100, 500); }           \
+        else { CALL(0, 0); }                                             \
+    } while (0)
 
 }  // namespace
 
 struct dcm_env {
     dcm_params p;
-    Layout L;
+    Lay L;
     KP kp;
     unsigned char* state = nullptr;  // [B][rec_bytes]
     double* summary = nullptr;       // [B][8]
@@ -989,11 +1056,11 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     dcm_env* h = new (std::nothrow) dcm_env();
     if (!h) return fail(DCM_ERR_INVALID, "dcm_create: out of host memory");
     h->p = *params;
-    h->L = make_layout(params->n_agents, params->n_tasks);
+    h->L = Lay{params->n_agents, params->n_tasks};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
-    if (h->L.lds_bytes > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
-    const size_t bytes = (size_t)params->n_envs * h->L.rec_bytes;
+    if (h->L.lds_bytes() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
+    const size_t bytes = (size_t)params->n_envs * h->L.rec_bytes();
     hipError_t e1 = hipMalloc((void**)&h->state, bytes);
     hipError_t e2 = hipMalloc((void**)&h->summary, (size_t)params->n_envs * 8 * sizeof(double));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1005,9 +1072,16 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     hipError_t e3 = hipMemset(h->state, 0, bytes);
     if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
     // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS
-    const void* ks[] = {(const void*)k_reset, (const void*)k_observe, (const void*)k_step, (const void*)k_rollout_random,
-                        (const void*)k_get_tasks, (const void*)k_get_agents};
-    for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->L.lds_bytes);
+    const int lds = (int)h->L.lds_bytes();
+#define SET_ATTR(CA, CT)                                                                                             \
+    (void)hipFuncSetAttribute((const void*)k_reset<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+    (void)hipFuncSetAttribute((const void*)k_observe<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+    (void)hipFuncSetAttribute((const void*)k_step<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
+    (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    DISPATCH_SHAPE(params->n_agents, params->n_tasks, SET_ATTR);
+#undef SET_ATTR
+    (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_get_agents, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = h;
     return DCM_OK;
 }
@@ -1024,13 +1098,14 @@ int dcm_destroy(dcm_env* env) {
 #define CHECK_ENV(env) \
     if (!(env)) return fail(DCM_ERR_INVALID, "null env handle")
 #define LAUNCH_OK() HIP_TRY(hipGetLastError())
+#define GRID(env) dim3((env)->p.n_envs), dim3(WAVE)
 
 int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy, const int32_t* req, const double* dur,
                        void* stream) {
     CHECK_ENV(env);
     if (!depot || !task_xy || !req || !dur) return fail(DCM_ERR_INVALID, "dcm_load_instances: null array");
-    hipLaunchKernelGGL(k_load_instances, dim3(env->p.n_envs), dim3(WAVE), 0, (hipStream_t)stream, env->L, env->state, depot,
-                       task_xy, req, dur);
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, env->L.A, env->L.T, env->state, depot, task_xy,
+                       req, dur);
     LAUNCH_OK();
     env->loaded = true;
     env->reset_done = false;
@@ -1041,8 +1116,11 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     CHECK_ENV(env);
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
-    hipLaunchKernelGGL(k_reset, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L, env->kp,
-                       env->state, seeds, env->summary);
+#define CALL(CA, CT)                                                                                                  \
+    hipLaunchKernelGGL((k_reset<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
+                       env->state, seeds, env->summary)
+    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+#undef CALL
     LAUNCH_OK();
     env->reset_done = true;
     return DCM_OK;
@@ -1052,8 +1130,11 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
                 uint8_t* active_out, const int32_t* leader_in, void* stream) {
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
-    hipLaunchKernelGGL(k_observe, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L, env->state,
-                       agents_out, tasks_out, mask_out, leader_out, active_out, leader_in);
+#define CALL(CA, CT)                                                                                                    \
+    hipLaunchKernelGGL((k_observe<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,     \
+                       env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in)
+    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+#undef CALL
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1066,9 +1147,12 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (!actions) return fail(DCM_ERR_INVALID, "dcm_step: null actions");
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
-    hipLaunchKernelGGL(k_step, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L, env->kp,
-                       env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out,
-                       active_out, env->summary);
+#define CALL(CA, CT)                                                                                                 \
+    hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
+                       env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
+                       active_out, env->summary)
+    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+#undef CALL
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1078,8 +1162,11 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, float* agents_out, float*
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
-    hipLaunchKernelGGL(k_rollout_random, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L,
-                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary);
+#define CALL(CA, CT)                                                                                                  \
+    hipLaunchKernelGGL((k_rollout_random<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, \
+                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary)
+    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+#undef CALL
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1095,8 +1182,8 @@ int dcm_summary(dcm_env* env, double* out, void* stream) {
 int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, double* now_out, void* stream) {
     CHECK_ENV(env);
     const int B = env->p.n_envs;
-    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L, env->state, B,
-                       flags_out, decisions_out, now_out);
+    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
+                       env->state, B, flags_out, decisions_out, now_out);
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1104,7 +1191,7 @@ int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, do
 int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* time_start, double* time_finish,
                   double* sum_wait, int32_t* status, int32_t* n_members, int32_t* n_abandoned, void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_tasks, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L, env->kp,
+    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned);
     LAUNCH_OK();
     return DCM_OK;
@@ -1113,7 +1200,7 @@ int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* ti
 int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* next_decision, double* arrival, double* x,
                    double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_agents, dim3(env->p.n_envs), dim3(WAVE), env->L.lds_bytes, (hipStream_t)stream, env->L, env->kp,
+    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current);
     LAUNCH_OK();
     return DCM_OK;
@@ -1122,14 +1209,14 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
 int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_ENV(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
-    *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes + (size_t)env->p.n_envs * 8 * sizeof(double);
+    *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double);
     return DCM_OK;
 }
 
 int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
     CHECK_ENV(env);
     if (!dst) return fail(DCM_ERR_INVALID, "dcm_clone_state: null dst");
-    const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes;
+    const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(dst, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb, env->summary, (size_t)env->p.n_envs * 8 * sizeof(double),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1139,7 +1226,7 @@ int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
 int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
     CHECK_ENV(env);
     if (!src) return fail(DCM_ERR_INVALID, "dcm_restore_state: null src");
-    const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes;
+    const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(env->state, src, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(env->summary, (const unsigned char*)src + sb, (size_t)env->p.n_envs * 8 * sizeof(double),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1161,7 +1248,7 @@ int dcm_distance(const double* ax, const double* ay, const double* bx, const dou
 int dcm_record_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_ENV(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
-    *bytes_out = env->L.rec_bytes;
+    *bytes_out = env->L.rec_bytes();
     return DCM_OK;
 }
 

@@ -73,10 +73,14 @@ uint64_t orc_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 uint64_t orc_env_seed(uint64_t base, uint64_t e) { return orc_mix64(base + ORC_GAMMA * (e + 1)); }
+/* 32-bit word `slot` of the decision's stream hi(key_1), lo(key_1), hi(key_2), lo(key_2), ... */
 uint64_t orc_draw(uint64_t seed_e, uint64_t d, uint64_t slot) {
     uint64_t key = orc_mix64(seed_e + ORC_GAMMA * (d + 1));
-    return orc_mix64(key + ORC_GAMMA * (slot + 1));
+    for (uint64_t i = 0; i < slot / 2; i++) key = orc_mix64(key + ORC_GAMMA);
+    return (slot % 2 == 0) ? (key >> 32) : (key & 0xFFFFFFFFULL);
 }
+/* multiply-high range reduction: r in [0,2^32) -> [0,n) */
+static int orc_below(uint64_t r, int n) { return (int)((r * (uint64_t)n) >> 32); }
 
 /* ------------------------------------------------------------------ numpy add.reduce (pairwise) */
 double orc_pairwise_sum(const double *a, int64_t n) {
@@ -481,7 +485,7 @@ static int policy_pick(orc_env *e, int policy, const uint8_t *mask, int leader, 
     if (policy == ORC_POLICY_RANDOM) {
         int nv = 0;
         for (int k = 0; k < T1; k++) nv += !mask[k];
-        int idx = (int)(orc_draw(seed_e, d, 1) % (uint64_t)nv);
+        int idx = orc_below(orc_draw(seed_e, d, 1), nv);
         for (int k = 0; k < T1; k++) if (!mask[k]) { if (idx == 0) return k; idx--; }
     } else if (policy == ORC_POLICY_FIRST) {
         for (int k = 0; k < T1; k++) if (!mask[k]) return k;
@@ -523,7 +527,7 @@ int64_t orc_rollout(orc_env *e, uint64_t seed_e, uint64_t d0, int policy, int64_
             for (int i = 0; i < n; i++) if (gof[i] == g) group[glen++] = ids[i];
             while (glen > 0) {                                              /* :53 */
                 if (step >= cap_steps) { step = -1; goto done; }
-                int leader = inj_leader ? inj_leader[step] : group[orc_draw(seed_e, d, 0) % (uint64_t)glen]; /* :54 */
+                int leader = inj_leader ? inj_leader[step] : group[orc_below(orc_draw(seed_e, d, 0), glen)]; /* :54 */
                 orc_mask(e, mask);                                          /* :57-61 */
                 orc_agent_status(e, leader, ag);                            /* :62 */
                 orc_task_status(e, leader, tk);                             /* :64 */
@@ -547,7 +551,7 @@ int64_t orc_rollout(orc_env *e, uint64_t seed_e, uint64_t d0, int policy, int64_
                             for (int i = 0; i < glen; i++) if (group[i] == f) pos = i;
                             if (pos < 0) { fprintf(stderr, "oracle: injected follower not in group\n"); abort(); }
                         } else {
-                            pos = (int)(orc_draw(seed_e, d, 2 + (uint64_t)j) % (uint64_t)glen);
+                            pos = orc_below(orc_draw(seed_e, d, 2 + (uint64_t)j), glen);
                         }
                         members[nm++] = group[pos];
                         memmove(group + pos, group + pos + 1, sizeof(int) * (glen - pos - 1)); glen--; /* :332-333 */

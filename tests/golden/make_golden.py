@@ -62,8 +62,15 @@ def env_seed(base, e):
 
 
 def draw(seed_e, d, s):
+    """32-bit word s of the decision's stream hi(key_1), lo(key_1), hi(key_2), ... (dcmrta_amd/choice.py)."""
     key = mix64(seed_e + GAMMA * (d + 1))
-    return mix64(key + GAMMA * (s + 1))
+    for _ in range(s // 2):
+        key = mix64(key + GAMMA)
+    return (key >> 32) if s % 2 == 0 else (key & 0xFFFFFFFF)
+
+
+def below(r, n):
+    return (r * n) >> 32
 
 
 # ----------------------------------------------------------------------------- instance helpers
@@ -90,7 +97,7 @@ def load_testset_env(i, max_waiting_time=10):
 # ----------------------------------------------------------------------------- policies
 def policy_random(env, mask, leader, seed_e, d):
     valid = np.flatnonzero(~mask)
-    return int(valid[draw(seed_e, d, 1) % len(valid)])
+    return int(valid[below(draw(seed_e, d, 1), len(valid))])
 
 
 def policy_first(env, mask, leader, seed_e, d):
@@ -125,7 +132,7 @@ def rollout(env, seed_e, policy, d0=0, record=True, quirks=None):
         k = int(np.asarray(size).reshape(-1)[0])
         out = []
         for j in range(k):
-            out.append(rest.pop(draw(seed_e, state["d"], 2 + j) % len(rest)))
+            out.append(rest.pop(below(draw(seed_e, state["d"], 2 + j), len(rest))))
         return np.array(out, dtype=np.int64)
 
     env.random_choice = injected_choice
@@ -148,7 +155,7 @@ def rollout(env, seed_e, policy, d0=0, record=True, quirks=None):
         for group in groups:  # :52
             while len(group) > 0:  # :53
                 d = state["d"]
-                leader = int(group[draw(seed_e, d, 0) % len(group)])  # :54, injected
+                leader = int(group[below(draw(seed_e, d, 0), len(group))])  # :54, injected
                 agent = env.agent_dic[leader]
                 assert not agent["returned"]  # :56
                 m = env.get_unfinished_task_mask()  # :57
@@ -201,7 +208,7 @@ def _follower_order(seed_e, d, before, leader, k):
     rest = [x for x in before if x != leader]
     out = []
     for j in range(k):
-        out.append(rest.pop(draw(seed_e, d, 2 + j) % len(rest)))
+        out.append(rest.pop(below(draw(seed_e, d, 2 + j), len(rest))))
     return out
 
 

@@ -36,9 +36,9 @@ def trace_hashes():
 
 def host_random_action(mask_row, seed_e, d):
     """Uniform-random valid action of the choice protocol (slot 1), host mirror."""
-    from dcmrta_amd.choice import draw
+    from dcmrta_amd.choice import below, draw
     valid = np.flatnonzero(mask_row == 0)
-    return int(valid[draw(seed_e, d, 1) % len(valid)])
+    return int(valid[below(draw(seed_e, d, 1), len(valid))])
 
 
 def run_lockstep(env, seeds, policy, inject=None, max_iters=100000):

@@ -1,0 +1,78 @@
+"""CPU, world_size=2, gloo: the N>1 path of bench.py / the runner -- contiguous env shards, no data-path
+collective, one all-gather of per-env episode returns.  Returns are produced by the oracle here
+(the HIP env cannot run without a GPU); what is under test is the sharding + gather logic in dcmrta_amd/dist.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import oracle
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.dist import DistContext, shard_range
+    from dcmrta_amd.instances import generate_batch
+    ctx = DistContext.from_env(expected_world=world, backend="gloo", device=torch.device("cpu"))
+    lo, hi = shard_range(n_total, rank, world)
+    inst = generate_batch(hi - lo, 5, 8, base_seed=11, first=lo)
+    seeds = env_seeds(3, lo, hi - lo)
+    _, reward, steps, _ = oracle.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"], seeds, 5)
+    gathered = ctx.all_gather_returns(torch.from_numpy(reward))
+    total = ctx.sum_over_ranks(int(steps.sum()))
+    tmax = ctx.max_over_ranks(float(rank + 1))
+    ctx.barrier()
+    q.put((rank, gathered.numpy().copy(), total, tmax, (lo, hi)))
+    ctx.shutdown()
+
+
+def test_shard_range_partitions():
+    from dcmrta_amd.dist import shard_range
+    for n in (1, 7, 8, 4096, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_all_gather_returns_world2(oracle_lib):
+    world, n_total = 2, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference over the unsharded batch
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    inst = generate_batch(n_total, 5, 8, base_seed=11)
+    _, reward, steps, _ = oracle_lib.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"],
+                                                   env_seeds(3, 0, n_total), 5)
+    for rank, gathered, total, tmax, (lo, hi) in res:
+        assert np.array_equal(gathered, reward), rank   # every rank holds the full return vector, rank-major
+        assert total == int(steps.sum())
+        assert tmax == float(world)
+    assert sorted(r[4] for r in res) == [(0, 6), (6, 12)]

@@ -137,7 +137,7 @@ def test_choice_protocol_mirrors(oracle_lib):
         assert choice.env_seeds(b, e, 2)[0] == choice.env_seed(b, e)
         s = choice.env_seed(b, e)
         for d in (0, 1, 119, 10**6):
-            for slot in (0, 1, 2, 5):
+            for slot in (0, 1, 2, 3, 5, 9):
                 assert oracle_lib.draw(s, d, slot) == choice.draw(s, d, slot)
 
 
