@@ -190,7 +190,8 @@ class BatchedTaskEnv:
         f8 = lambda: torch.empty((B, A), dtype=torch.float64, device=dev)
         u8 = lambda: torch.empty((B, A), dtype=torch.uint8, device=dev)
         o = dict(sum_waiting_time=f8(), travel_dist=f8(), next_decision=f8(), arrival=f8(), x=f8(), y=f8(),
-                 returned=u8(), assigned=u8(), current=torch.empty((B, A), dtype=torch.int32, device=dev))
+                 returned=u8(), assigned=u8(), current=torch.empty((B, A), dtype=torch.int32, device=dev),
+                 pending_group=torch.empty((B, A), dtype=torch.int32, device=dev))
         with torch.cuda.device(dev):
             check(self._lib.dcm_get_agents(self._h, *[_ptr(v) for v in o.values()], self._stream()))
         return o

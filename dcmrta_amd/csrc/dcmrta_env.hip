@@ -973,7 +973,7 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned
 __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
-                                                    int32_t* current) {
+                                                    int32_t* current, int32_t* pending) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<0, 0> S{A, T, smem};
     const Lay L = S.L();
@@ -993,6 +993,7 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigne
         if (returned) returned[o] = (ai & A_RETURNED) ? 1 : 0;
         if (assigned) assigned[o] = (ai & A_ASSIGNED) ? 1 : 0;
         if (current) current[o] = S.cur()[a];
+        if (pending) pending[o] = (int32_t)((ai >> 8) & 0xFFu);
     }
 }
 
@@ -1198,10 +1199,12 @@ int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* ti
 }
 
 int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* next_decision, double* arrival, double* x,
-                   double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, void* stream) {
+                   double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, int32_t* pending_group,
+                   void* stream) {
     CHECK_ENV(env);
     hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
-                       env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current);
+                       env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
+                       pending_group);
     LAUNCH_OK();
     return DCM_OK;
 }

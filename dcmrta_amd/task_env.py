@@ -1,0 +1,235 @@
+"""TaskEnv -- the reference's per-env method surface (env/task_env.py:8-623) on top of the HIP env.
+
+A single-env (B=1) view with the attribute and method names worker.py / RL_test.py call, so a loop written
+against the reference class (worker.py:45-87) runs unchanged:
+
+    decision_agents, t = env.next_decision();  groups = env.get_unique_group(decision_agents)
+    env.current_time = t;  env.task_update();  env.agent_update()
+    ... mask = env.get_unfinished_task_mask(); env.get_current_agent_status(agent); env.get_current_task_status(agent)
+    group, r = env.step(group, leader_id, action, idx);  env.task_update();  env.agent_update()
+    env.finished = env.check_finished()
+    reward, finished_tasks = env.get_episode_reward(MAX_TIME)
+
+The HIP kernels fuse step + task_update + agent_update + check_finished + next event, so this adapter
+answers the fine-grained calls from the already-advanced device state: task_update / agent_update are
+no-ops (the device applied them), next_decision / get_unique_group report the deciding groups the device
+computed, and current_time only moves forward when the caller commits it (`env.current_time = t`,
+worker.py:49), which keeps the `current_time < MAX_TIME` loop test of worker.py:45 on the previous event's time
+exactly like the reference (quirk Q7).  It is a compatibility surface for the reference's call pattern, not a
+general re-implementation of every call order; use BatchedTaskEnv for throughput.
+
+Differences a caller can observe: observations are the fp32 values the policy receives (the reference returns
+fp64 and casts at worker.py:62,64); followers are drawn by the keyed choice protocol instead of numpy's RNG.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .batched_env import BatchedTaskEnv
+from .instances import generate_instance
+
+
+class TaskEnv:
+    def __init__(self, agents_range=(10, 10), tasks_range=(10, 10), traits_dim=1, max_coalition_size=3, max_duration=5,
+                 seed=None, plot_figure=False, device="cuda:0", choice_seed=0):
+        if traits_dim != 1:
+            raise NotImplementedError("traits_dim != 1 does not work in the reference either (SURVEY.md §5)")
+        if max_coalition_size > _lib.MAX_MEMBERS:
+            raise ValueError(f"max_coalition_size <= {_lib.MAX_MEMBERS}")
+        rng = np.random.default_rng(seed)
+        # env/task_env.py:58-65: sizes are drawn first when ranges are tuples
+        T = int(rng.integers(tasks_range[0], tasks_range[1] + 1)) if isinstance(tasks_range, tuple) else int(tasks_range)
+        A = int(rng.integers(agents_range[0], agents_range[1] + 1)) if isinstance(agents_range, tuple) else int(agents_range)
+        depot = rng.random((1, 2))[0]
+        rng.random((A, 1))
+        task_xy = rng.random((T, 2))
+        req = rng.integers(1, max_coalition_size + 1, T).astype(np.int32)
+        dur = np.full(T, float(max_duration))
+        self._init_from_arrays(A, depot, task_xy, req, dur, device, choice_seed)
+
+    @classmethod
+    def from_arrays(cls, n_agents, depot, task_xy, req, dur, device="cuda:0", choice_seed=0, max_waiting_time=10.0):
+        self = cls.__new__(cls)
+        self._init_from_arrays(int(n_agents), np.asarray(depot, np.float64), np.asarray(task_xy, np.float64),
+                               np.asarray(req, np.int32), np.asarray(dur, np.float64), device, choice_seed,
+                               max_waiting_time)
+        return self
+
+    def _init_from_arrays(self, A, depot, task_xy, req, dur, device, choice_seed, max_waiting_time=10.0):
+        self.agents_num, self.tasks_num = A, len(req)
+        self.max_waiting_time = float(max_waiting_time)
+        self.reactive_planning = False
+        self.dt = 0.1
+        self._inst = (depot.copy(), task_xy.copy(), req.copy(), dur.copy())
+        self._env = BatchedTaskEnv(1, A, self.tasks_num, device=device, max_waiting_time=self.max_waiting_time)
+        self._env.load_instances(depot[None], task_xy[None], req[None], dur[None])
+        self._seed = np.array([choice_seed], dtype=np.uint64)
+        self.depot = {"location": depot.copy(), "members": [], "ID": -1}
+        self.clear_decisions()
+
+    # ------------------------------------------------------------------ reset (env/task_env.py:116-140)
+    def reset(self, test_env=None, seed=None):
+        if test_env is not None:
+            raise NotImplementedError("swap instances with TaskEnv.from_arrays(...)")
+        if seed is not None:
+            self._seed = np.array([seed], dtype=np.uint64)
+        self.clear_decisions()
+
+    def clear_decisions(self):
+        self._env.reset(self._seed, observe=False)
+        self.finished = False
+        self._visible_time = 0.0
+        self._dirty = True
+
+    # ------------------------------------------------------------------ device state cache
+    def _sync(self):
+        if not self._dirty:
+            return
+        st = self._env.status()
+        self._flags = int(st["flags"][0])
+        self._now = float(st["now"][0])
+        self._decisions = int(st["decisions"][0])
+        ag = {k: v[0].cpu().numpy() for k, v in self._env.agents_state().items()}
+        tk = {k: v[0].cpu().numpy() for k, v in self._env.tasks_state().items()}
+        self._ag, self._tk = ag, tk
+        obs = self._env.observe()
+        self._leader_dev = int(obs.leader[0])
+        if self._flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER):
+            raise RuntimeError(f"env error flags {self._flags:#x}")
+        if self._flags & _lib.FLAG_TRUNCATED:
+            raise RuntimeError("every agent is at the depot while a task can never become feasible: the reference "
+                               "loops forever here (SURVEY.md §5); the device env truncated the episode")
+        self._dirty = False
+
+    @property
+    def _done(self):
+        self._sync()
+        return bool(self._flags & _lib.FLAG_DONE)
+
+    # current_time: the caller commits the new event time (worker.py:49)
+    @property
+    def current_time(self):
+        self._sync()
+        return self._now if self._done else self._visible_time
+
+    @current_time.setter
+    def current_time(self, t):
+        self._visible_time = float(t)
+
+    @property
+    def agent_dic(self):
+        self._sync()
+        a = self._ag
+        return {i: {"ID": i, "location": np.array([a["x"][i], a["y"][i]]), "returned": bool(a["returned"][i]),
+                    "assigned": bool(a["assigned"][i]), "next_decision": float(a["next_decision"][i]),
+                    "travel_dist": float(a["travel_dist"][i]), "sum_waiting_time": float(a["sum_waiting_time"][i]),
+                    "velocity": 0.2, "depot": self.depot["location"]} for i in range(self.agents_num)}
+
+    @property
+    def task_dic(self):
+        self._sync()
+        t = self._tk
+        _, xy, req, dur = self._inst
+        return {i: {"ID": i, "requirements": np.array([req[i]]), "location": xy[i].copy(), "time": float(dur[i]),
+                    "feasible_assignment": bool(t["feasible"][i]), "finished": bool(t["finished"][i]),
+                    "time_start": float(t["time_start"][i]), "time_finish": float(t["time_finish"][i]),
+                    "status": np.array([int(t["status"][i])]), "sum_waiting_time": float(t["sum_waiting_time"][i]),
+                    "n_members": int(t["n_members"][i]), "n_abandoned": int(t["n_abandoned"][i])}
+                for i in range(self.tasks_num)}
+
+    @staticmethod
+    def get_matrix(dictionary, key):  # env/task_env.py:150-159
+        return [v[key] for v in dictionary.values()]
+
+    # ------------------------------------------------------------------ event queries (env/task_env.py:283-298)
+    def _pending_groups(self):
+        """Groups of the current event that still have to decide, in the device's (x, y) order."""
+        self._sync()
+        if self._done:
+            return []
+        pg = self._ag["pending_group"]  # 0 = not deciding, g = index of its group (np.unique order, :293)
+        return [[a for a in range(self.agents_num) if pg[a] == g] for g in sorted(set(pg[pg > 0].tolist()))]
+
+    def next_decision(self):
+        self._sync()
+        if self._done:
+            arr = [self._ag["arrival"][a] if self._ag["current"][a] != -2 else 0 for a in range(self.agents_num)]
+            return [], max(arr)
+        ids = np.array(sorted(a for g in self._pending_groups() for a in g), dtype=np.int64)
+        return ids, self._now
+
+    def get_unique_group(self, agents):
+        want = set(int(a) for a in agents)
+        return [[a for a in g if a in want] for g in self._pending_groups() if any(a in want for a in g)]
+
+    def task_update(self):  # applied on the device inside dcm_reset / dcm_step (worker.py:50,74)
+        return []
+
+    def agent_update(self):  # idem (worker.py:51,76)
+        return None
+
+    # ------------------------------------------------------------------ observations (env/task_env.py:165-200)
+    def _observe(self, leader):
+        return self._env.observe(leader=np.array([leader], np.int32))
+
+    def get_unfinished_task_mask(self):
+        self._sync()
+        t = self._tk
+        return np.logical_not((t["feasible"] == 0) & (t["status"] > 0))
+
+    def get_current_agent_status(self, agent):
+        return self._observe(agent["ID"]).agents[0].cpu().numpy().astype(np.float64)
+
+    def get_current_task_status(self, agent):
+        return self._observe(agent["ID"]).tasks[0].cpu().numpy().astype(np.float64)
+
+    # ------------------------------------------------------------------ step (env/task_env.py:326-342)
+    def step(self, group, leader_id, action, current_action_index=0):
+        self._sync()
+        before = self._ag
+        pos0 = np.stack([before["x"], before["y"]], 1).copy()
+        gid = int(before["pending_group"][leader_id])
+        n_before = self._decisions
+        self._env.step(np.array([action], np.int32), leader=np.array([leader_id], np.int32), observe=False)
+        self._dirty = True
+        self._sync()
+        # members of this step = agents of the group that left the pending set; once the event is over
+        # (new event or terminal) the whole remaining group has left
+        same_event = (not self._done) and self._now == self._visible_time and \
+            any(int(self._ag["pending_group"][a]) == gid for a in group if a != leader_id)
+        moved = [a for a in group if a == leader_id or not same_event or int(self._ag["pending_group"][a]) != gid]
+        if self._decisions == n_before:
+            raise RuntimeError("leader is not in the deciding group")
+        target = self.depot["location"] if action == 0 else self._inst[1][action - 1]
+        tt = [float(np.linalg.norm(pos0[a] - target)) / 0.2 for a in moved] or [0.0]
+        for a in moved:
+            if a in group:
+                group.remove(a)
+        return group, -float(np.mean(tt))
+
+    def agent_step(self, agent_id, task_id):
+        """Individual selection (worker.py:186): the agent acts alone, no followers."""
+        self._sync()
+        self._env.step(np.array([task_id], np.int32), leader=np.array([agent_id], np.int32),
+                       n_followers=np.array([0], np.int32), followers=np.full((1, 4), -1, np.int16), observe=False)
+        self._dirty = True
+
+    # ------------------------------------------------------------------ termination (env/task_env.py:366-373,420-425)
+    def check_finished(self):
+        self._sync()
+        return bool(self._flags & _lib.FLAG_FINISHED)
+
+    def get_episode_reward(self, max_time=100):
+        self._sync()
+        if not self._done:
+            raise RuntimeError("episode still running: the device env computes the reward at its terminal state")
+        return -self._now, [bool(f) for f in self._tk["finished"]]
+
+    def perf_metrics(self):
+        """worker.py:103-108."""
+        sm = self._env.summary()[0].cpu().numpy()
+        return dict(success_rate=sm[2], makespan=sm[3], time_cost=sm[4], waiting_time=sm[5], travel_dist=sm[6],
+                    efficiency=sm[7])
+
+    def pre_set_route(self, routes, agent_id):
+        raise NotImplementedError("route replay runs through BatchedTaskEnv.execute_routes")

@@ -128,11 +128,14 @@ int dcm_env_status(dcm_env *env, uint32_t *flags_out, int64_t *decisions_out, do
 
 /* Per-task / per-agent state for parity tests and the per-env facade (any pointer may be NULL):
  * tasks: finished,feasible u8[B,T]; time_start,time_finish,sum_waiting_time f64[B,T]; status,n_members,n_abandoned i32[B,T]
- * agents: sum_waiting_time,travel_dist,next_decision,arrival f64[B,A]; x,y f64[B,A]; returned,assigned u8[B,A]; current i32[B,A] (-2 none,-1 depot) */
+ * agents: sum_waiting_time,travel_dist,next_decision,arrival f64[B,A]; x,y f64[B,A]; returned,assigned u8[B,A];
+ *         current i32[B,A] (route[-1]: -2 none, -1 depot, k task); pending_group i32[B,A] (0 = not deciding in this
+ *         event, g >= 1 = index of its group in get_unique_group order, env/task_env.py:291-298) */
 int dcm_get_tasks(dcm_env *env, uint8_t *finished, uint8_t *feasible, double *time_start, double *time_finish,
                   double *sum_wait, int32_t *status, int32_t *n_members, int32_t *n_abandoned, void *stream);
 int dcm_get_agents(dcm_env *env, double *sum_wait, double *travel_dist, double *next_decision, double *arrival,
-                   double *x, double *y, uint8_t *returned, uint8_t *assigned, int32_t *current, void *stream);
+                   double *x, double *y, uint8_t *returned, uint8_t *assigned, int32_t *current,
+                   int32_t *pending_group, void *stream);
 
 /* copy.deepcopy(env) (worker.py:33): snapshot / restore of the mutable SoA state.
  * dcm_state_bytes gives the buffer size (device memory) needed for all B envs. */

@@ -1,0 +1,91 @@
+"""-m gpu: the reference's per-env call pattern (worker.py:45-87) driven against dcmrta_amd.task_env.TaskEnv.
+
+The loop below is the same harness tests/golden/make_golden.py runs against the *reference* TaskEnv (duck-typed:
+next_decision / get_unique_group / task_update / agent_update / mask / status / step / check_finished /
+get_episode_reward), so equality with the golden traces shows the facade is a drop-in for that call pattern."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+MAX_TIME = 100
+
+
+def worker_loop(env, seed_e, policy):
+    from dcmrta_amd.choice import below, draw
+    T = env.tasks_num
+    rec = dict(leader=[], action=[], now=[], mask=[], agents_obs=[], tasks_obs=[])
+    d = 0
+    while not env.finished and env.current_time < MAX_TIME:            # worker.py:45
+        decision_agents, current_time = env.next_decision()           # :47
+        groups = env.get_unique_group(decision_agents)                # :48
+        env.current_time = current_time                               # :49
+        env.task_update()                                             # :50
+        env.agent_update()                                            # :51
+        for group in groups:                                          # :52
+            while len(group) > 0:                                     # :53
+                leader_id = int(group[below(draw(seed_e, d, 0), len(group))])   # :54 (protocol instead of np.random)
+                agent = env.agent_dic[leader_id]
+                assert not agent["returned"]                          # :56
+                mask = env.get_unfinished_task_mask()                 # :57
+                mask = np.insert(mask, 0, False if np.sum(mask) == T else True)  # :58-61
+                total_agents = env.get_current_agent_status(agent).astype(np.float32)   # :62
+                task_info = env.get_current_task_status(agent).astype(np.float32)       # :64
+                action = policy(d, mask)
+                rec["leader"].append(leader_id); rec["action"].append(action); rec["now"].append(env.current_time)
+                rec["mask"].append(mask.astype(np.uint8)); rec["agents_obs"].append(total_agents); rec["tasks_obs"].append(task_info)
+                group, r = env.step(group, leader_id, action, d)      # :73
+                env.task_update()                                     # :74
+                env.agent_update()                                    # :76
+                d += 1
+        env.finished = env.check_finished()                           # :85
+    reward, finished_tasks = env.get_episode_reward(MAX_TIME)         # :87
+    return rec, reward, finished_tasks
+
+
+@pytest.mark.parametrize("name", ["trace_5A8T_random_s0", "trace_5A8T_nearest_s1", "trace_10A20T_random_s1",
+                                  "trace_20A50T_random_s0", "trace_20A50T_nearest_s0", "trace_20A50T_first_s1"])
+def test_worker_loop_on_facade(gpu_device, golden_dir, name):
+    from dcmrta_amd.task_env import TaskEnv
+    tr = H.load_trace(os.path.join(golden_dir, name + ".npz"))
+    env = TaskEnv.from_arrays(int(tr["A"]), tr["depot"], tr["task_xy"], tr["req"], tr["dur"], device=gpu_device,
+                              choice_seed=int(tr["seed_e"]))
+    rec, reward, finished = worker_loop(env, int(tr["seed_e"]), lambda d, mask: int(tr["action"][d]))
+    n = int(tr["n_steps"])
+    assert len(rec["leader"]) == n
+    assert np.array_equal(np.array(rec["leader"]), tr["leader"])
+    assert np.array_equal(np.array(rec["now"]), tr["now"])
+    assert np.array_equal(np.stack(rec["mask"]), tr["mask"])
+    assert np.array_equal(np.stack(rec["agents_obs"]), tr["agents_obs"])
+    assert np.array_equal(np.stack(rec["tasks_obs"]), tr["tasks_obs"])
+    assert reward == float(tr["reward"])
+    assert np.array_equal(np.array(finished, np.uint8), tr["finished"])
+    m = env.perf_metrics()
+    for i, k in enumerate(("success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency")):
+        if k == "waiting_time":
+            np.testing.assert_allclose(m[k], tr["metrics"][i], rtol=1e-12)
+        else:
+            assert m[k] == tr["metrics"][i], k
+    # dict views carry the reference's keys
+    assert set(("location", "returned", "assigned", "travel_dist")) <= set(env.agent_dic[0])
+    assert set(("feasible_assignment", "finished", "time_start", "time_finish", "status", "requirements")) <= set(env.task_dic[0])
+
+
+def test_step_returns_group_and_reward(gpu_device):
+    from dcmrta_amd.task_env import TaskEnv
+    env = TaskEnv((6, 6), (9, 9), 1, 5, seed=3, device=gpu_device, choice_seed=5)
+    ids, t = env.next_decision()
+    assert t == 0.0 and list(ids) == list(range(6))
+    groups = env.get_unique_group(ids)
+    assert groups == [list(range(6))]
+    group = groups[0]
+    mask = env.get_unfinished_task_mask()
+    assert mask.shape == (9,) and not mask.any()
+    n0 = len(group)
+    group, r = env.step(group, 2, 1, 0)
+    assert 2 not in group and len(group) < n0 and r <= 0.0
+    with pytest.raises(RuntimeError):
+        env.step(group, 2, 1, 0)   # agent 2 is no longer deciding
