@@ -16,7 +16,7 @@ MAX_MEMBERS = 5
 MAX_AGENTS = 128
 MAX_TASKS = 1023
 
-FLAG_DONE, FLAG_FINISHED, FLAG_TRUNCATED, FLAG_BAD_ACTION, FLAG_OVERFLOW, FLAG_BAD_LEADER = 1, 2, 4, 8, 16, 32
+FLAG_DONE, FLAG_FINISHED, FLAG_TRUNCATED, FLAG_BAD_ACTION, FLAG_OVERFLOW, FLAG_BAD_LEADER, FLAG_TYPE_ERROR = 1, 2, 4, 8, 16, 32, 64
 
 
 class DcmParams(C.Structure):
@@ -50,6 +50,8 @@ SIGNATURES = {
     "dcm_restore_state": (C.c_int, [_vp] * 3),
     "dcm_distance": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dcm_record_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "dcm_load_routes": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "dcm_execute_routes": (C.c_int, [_vp, _i32] + [_vp] * 11),
 }
 
 _LIB = None

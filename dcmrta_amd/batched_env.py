@@ -196,6 +196,42 @@ class BatchedTaskEnv:
             check(self._lib.dcm_get_agents(self._h, *[_ptr(v) for v in o.values()], self._stream()))
         return o
 
+    # ------------------------------------------------------------------ route replay (env/task_env.py:562-599)
+    def load_routes(self, routes, member_cap=8):
+        """routes[b][a] = list of actions (0 = depot, k = task k-1) or None (pre_set_route stays None)."""
+        B, A = self.B, self.A
+        cap = max([len(r) for env in routes for r in env if r is not None] + [1])
+        arr = np.zeros((B, A, cap), np.int32)
+        ln = np.full((B, A), -1, np.int32)
+        for b in range(B):
+            for a in range(A):
+                r = routes[b][a] if a < len(routes[b]) else None
+                if r is not None:
+                    ln[b, a] = len(r)
+                    arr[b, a, :len(r)] = r
+        d_arr, d_ln = self._dev(arr, torch.int32), self._dev(ln, torch.int32)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_load_routes(self._h, _ptr(d_arr), _ptr(d_ln), cap, int(member_cap), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        return self
+
+    def execute_routes(self, reactive=False):
+        """execute_by_route + get_episode_reward for every env; returns a dict of device tensors."""
+        B, A, T, dev = self.B, self.A, self.T, self.device
+        o = dict(steps=torch.empty((B,), dtype=torch.int64, device=dev), flags=torch.empty((B,), dtype=torch.int32, device=dev),
+                 finished=torch.empty((B, T), dtype=torch.uint8, device=dev),
+                 time_start=torch.empty((B, T), dtype=torch.float64, device=dev),
+                 time_finish=torch.empty((B, T), dtype=torch.float64, device=dev),
+                 task_wait=torch.empty((B, T), dtype=torch.float64, device=dev),
+                 n_members=torch.empty((B, T), dtype=torch.int32, device=dev),
+                 agent_wait=torch.empty((B, A), dtype=torch.float64, device=dev),
+                 travel_dist=torch.empty((B, A), dtype=torch.float64, device=dev),
+                 returned=torch.empty((B, A), dtype=torch.uint8, device=dev))
+        with torch.cuda.device(dev):
+            check(self._lib.dcm_execute_routes(self._h, int(bool(reactive)), *[_ptr(v) for v in o.values()], self._stream()))
+        o["summary"] = self.summary()
+        return o
+
     # ------------------------------------------------------------------ snapshot (copy.deepcopy(env), worker.py:33)
     def clone_state(self):
         n = C.c_size_t()

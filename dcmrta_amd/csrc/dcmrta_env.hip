@@ -19,185 +19,19 @@
 //
 // Reference restated: env/task_env.py (TaskEnv) and worker.py:41-112 (the rollout loop).
 // Every device function cites the lines it follows.
-#include <hip/hip_runtime.h>
+#include "common.hpp"
 
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <new>
+using namespace dcm;
 
-#include "../../include/dcmrta_env.h"
+namespace dcm {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, const char* a, const char* b) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+}  // namespace dcm
 
 namespace {
-
-constexpr int WAVE = 64;
-constexpr int M = DCM_MAX_MEMBERS;
-constexpr int AW_MAX = (DCM_MAX_AGENTS + 63) / 64;  // 64-bit words of an agent bitmask
-
-// ---------------------------------------------------------------------------------- record
-struct Hdr {  // 64 B header of an env record
-    double now;            // current_time, env/task_env.py:28
-    uint64_t seed;         // choice-protocol seed of this env
-    uint64_t d;            // running decision counter (key of the choice protocol)
-    double depot_x, depot_y;  // depot['location'] :111
-    uint32_t flags;        // DCM_FLAG_*
-    int32_t cur_group;     // 1-based index of the group now deciding (worker.py:52), 0 = none
-    int32_t n_groups;      // groups of the current event (env/task_env.py:291-298)
-    int32_t empty_passes;  // consecutive zero-decider events (guard)
-    uint32_t ep_steps;     // decisions in the current episode
-    uint32_t episodes;     // finished episodes since dcm_reset
-};
-static_assert(sizeof(Hdr) == 64, "header must be 64 bytes");
-
-// ainfo[a]: bit0 returned, bit1 assigned, bit2 in depot['members'], bit3 listed in members of route[-1],
-//           bits 8-15 pending group id, bits 16-31 number of times moved to an abandoned_agent list
-constexpr uint32_t A_RETURNED = 1u, A_ASSIGNED = 2u, A_INDEPOT = 4u, A_MEMBER = 8u, A_GRP = 0xFF00u;
-// tinfo[t]: bits 0-7 requirements, 8-15 status (int8, may be stale: quirk Q3), 16-23 len(members),
-//           bit 24 feasible_assignment, bit 25 finished
-constexpr uint32_t T_FEAS = 1u << 24, T_FIN = 1u << 25;
-
-__host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
-// Record layout as a function of (A,T); see DESIGN.md §3.  All sections 8-byte aligned.
-struct Lay {
-    int A, T;
-    __host__ __device__ constexpr uint32_t ax() const { return 64; }                 // f64[A] location x
-    __host__ __device__ constexpr uint32_t ay() const { return 64 + 8 * A; }         // f64[A] location y
-    __host__ __device__ constexpr uint32_t arr() const { return 64 + 16 * A; }       // f64[A] arrival_time[-1]
-    __host__ __device__ constexpr uint32_t nd() const { return 64 + 24 * A; }        // f64[A] next_decision
-    __host__ __device__ constexpr uint32_t tdist() const { return 64 + 32 * A; }     // f64[A] travel_dist
-    __host__ __device__ constexpr uint32_t cur() const { return 64 + 40 * A; }       // i32[A] route[-1]
-    __host__ __device__ constexpr uint32_t ainfo() const { return 64 + 44 * A; }     // u32[A]
-    __host__ __device__ constexpr uint32_t tb() const { return 64 + 48 * A; }
-    __host__ __device__ constexpr uint32_t ts() const { return tb(); }               // f64[T] time_start
-    __host__ __device__ constexpr uint32_t tf() const { return tb() + 8 * T; }       // f64[T] time_finish
-    __host__ __device__ constexpr uint32_t marr() const { return tb() + 16 * T; }    // f64[M][T] member arrivals
-    __host__ __device__ constexpr uint32_t mids() const { return tb() + 56 * T; }    // u64[T] ordered member ids
-    __host__ __device__ constexpr uint32_t tinfo() const { return tb() + 64 * T; }   // u32[T]
-    __host__ __device__ constexpr uint32_t tnab() const { return tb() + 68 * T; }    // u32[T] len(abandoned_agent)
-    __host__ __device__ constexpr uint32_t mut_bytes() const { return align16(tb() + 72 * T); }
-    __host__ __device__ constexpr uint32_t tx() const { return mut_bytes(); }        // f64[T] task x (instance)
-    __host__ __device__ constexpr uint32_t ty() const { return mut_bytes() + 8 * T; }
-    __host__ __device__ constexpr uint32_t tdur() const { return mut_bytes() + 16 * T; }
-    __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
-    __host__ __device__ constexpr uint32_t tw() const { return rec_bytes(); }        // scratch f64[T] (LDS only)
-    __host__ __device__ constexpr uint32_t aw() const { return rec_bytes() + 8 * T; }  // scratch f64[A]
-    __host__ __device__ constexpr uint32_t lds_bytes() const { return align16(rec_bytes() + 8 * T + 8 * A); }
-};
-static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
-
-struct KP {
-    double mwt;       // max_waiting_time
-    double max_time;  // MAX_TIME
-};
-
-extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-#define WSYNC() __syncthreads() /* 64-thread workgroup: lowers to a wave barrier + LDS wait */
-
-// ---------------------------------------------------------------------------------- uniform helpers
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t uni(uint64_t v) {
-    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
-__device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((uint64_t)__double_as_longlong(v))); }
-
-__device__ __forceinline__ Hdr load_hdr(const unsigned char* p) {
-    const Hdr* q = (const Hdr*)p;
-    Hdr h;
-    h.now = uni(q->now); h.seed = uni(q->seed); h.d = uni(q->d); h.depot_x = uni(q->depot_x); h.depot_y = uni(q->depot_y);
-    h.flags = uni(q->flags); h.cur_group = uni(q->cur_group); h.n_groups = uni(q->n_groups);
-    h.empty_passes = uni(q->empty_passes); h.ep_steps = uni(q->ep_steps); h.episodes = uni(q->episodes);
-    return h;
-}
-
-// ---------------------------------------------------------------------------------- choice protocol
-// dcmrta_amd/choice.py: stream of 32-bit words hi(key_1), lo(key_1), hi(key_2), ...;
-// slot 0 leader, 1 action, 2+j follower j; below(r,n) = (r*n) >> 32.  All wave-uniform.
-constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ULL;
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint64_t key1(uint64_t seed, uint64_t d) { return mix64(seed + GAMMA * (d + 1)); }
-__device__ __forceinline__ int below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)(uint32_t)n) >> 32); }
-
-// ---------------------------------------------------------------------------------- wave reductions (DPP)
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);  // lanes without a source keep their own value
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// NaN-ignoring minimum over the wave (np.nanmin), NaN when every lane is NaN.  fmin/fmax are exact.
-__device__ __forceinline__ double wave_nanmin(double v) {
-    v = fmin(v, dpp_f64<0x111, 0xF>(v));  // row_shr:1
-    v = fmin(v, dpp_f64<0x112, 0xF>(v));  // row_shr:2
-    v = fmin(v, dpp_f64<0x114, 0xF>(v));  // row_shr:4
-    v = fmin(v, dpp_f64<0x118, 0xF>(v));  // row_shr:8  -> lane 15 of each row holds the row minimum
-    v = fmin(v, dpp_f64<0x142, 0xA>(v));  // row_bcast:15 into rows 1,3
-    v = fmin(v, dpp_f64<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave minimum
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_nanmax(double v) {
-    v = fmax(v, dpp_f64<0x111, 0xF>(v));
-    v = fmax(v, dpp_f64<0x112, 0xF>(v));
-    v = fmax(v, dpp_f64<0x114, 0xF>(v));
-    v = fmax(v, dpp_f64<0x118, 0xF>(v));
-    v = fmax(v, dpp_f64<0x142, 0xA>(v));
-    v = fmax(v, dpp_f64<0x143, 0xC>(v));
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-// position of the idx-th (0-based) set bit of a wave-uniform mask; all 64 lanes must call
-__device__ __forceinline__ int nth_set_bit(uint64_t m, int idx, int lane) {
-    const bool b = (m >> lane) & 1ull;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    const uint64_t sel = __ballot(b && rank == idx);
-    return __ffsll((unsigned long long)sel) - 1;
-}
-
-// ---------------------------------------------------------------------------------- numpy add.reduce
-// np.sum / np.mean use pairwise summation (8 accumulators per <=128-element block, recursive
-// halving above); restated so the perf metrics of worker.py:103-108 are bit-identical.
-__device__ __noinline__ double psum_block(const double* a, int n) {
-    if (n < 8) {
-        double r = 0.;
-        for (int i = 0; i < n; i++) r += a[i];
-        return r;
-    }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += a[i];
-    return res;
-}
-template <int DEPTH>
-__device__ double psum(const double* a, int n) {
-    if constexpr (DEPTH == 0) {
-        return psum_block(a, n);
-    } else {
-        if (n <= 128) return psum_block(a, n);
-        int n2 = n / 2;
-        n2 -= n2 % 8;
-        return psum<DEPTH - 1>(a, n2) + psum<DEPTH - 1>(a + n2, n - n2);
-    }
-}
-
-// env/task_env.py:161-163 -- np.linalg.norm of a 2-vector == sqrt(fma(dy,dy,dx*dx)) on the
-// reference machine (tests/golden/distance_kat.npz).
-__device__ __forceinline__ double dist2(double ax, double ay, double bx, double by) {
-    const double dx = ax - bx, dy = ay - by;
-    return sqrt(__builtin_fma(dy, dy, dx * dx));
-}
 
 // ================================================================================== the simulator
 template <int CA, int CT>
@@ -766,16 +600,6 @@ struct Sim {
     }
 };
 
-// ---------------------------------------------------------------------------------- record I/O
-__device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
-    const uint4* s = (const uint4*)src;
-    uint4* d = (uint4*)dst;
-    for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = s[i];
-}
-__device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
-    if (lane == 0) *(Hdr*)smem = h;
-}
-
 // ---------------------------------------------------------------------------------- kernels
 __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned char* state, const double* depot,
                                                         const double* task_xy, const int32_t* req, const double* dur) {
@@ -1007,17 +831,6 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
 }
 
 // ---------------------------------------------------------------------------------- host side
-thread_local char g_err[512] = "";
-int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
-    snprintf(g_err, sizeof(g_err), fmt, a, b);
-    return code;
-}
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess) return fail(DCM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-    } while (0)
-
 // shape dispatch: BASELINE shapes get the constant-offset instantiation
 #define DISPATCH_SHAPE(A, T, CALL)                                       \
     do {                                                                 \
@@ -1029,18 +842,9 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
 
 }  // namespace
 
-struct dcm_env {
-    dcm_params p;
-    Lay L;
-    KP kp;
-    unsigned char* state = nullptr;  // [B][rec_bytes]
-    double* summary = nullptr;       // [B][8]
-    bool loaded = false, reset_done = false;
-};
-
 extern "C" {
 
-const char* dcm_last_error(void) { return g_err; }
+const char* dcm_last_error(void) { return dcm::g_err; }
 int dcm_abi_version(void) { return DCM_ABI_VERSION; }
 
 int dcm_create(const dcm_params* params, dcm_env** out) {
@@ -1092,14 +896,12 @@ int dcm_destroy(dcm_env* env) {
     (void)hipSetDevice(env->p.device);
     if (env->state) (void)hipFree(env->state);
     if (env->summary) (void)hipFree(env->summary);
+    if (env->routes) (void)hipFree(env->routes);
+    if (env->route_len) (void)hipFree(env->route_len);
     delete env;
     return DCM_OK;
 }
 
-#define CHECK_ENV(env) \
-    if (!(env)) return fail(DCM_ERR_INVALID, "null env handle")
-#define LAUNCH_OK() HIP_TRY(hipGetLastError())
-#define GRID(env) dim3((env)->p.n_envs), dim3(WAVE)
 
 int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy, const int32_t* req, const double* dur,
                        void* stream) {

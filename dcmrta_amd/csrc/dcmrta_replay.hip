@@ -1,0 +1,459 @@
+// dcmrta_replay.hip -- route replay with optional dynamic task visibility on MI355X (gfx950).
+//
+// Restates TaskEnv.pre_set_route / execute_by_route (env/task_env.py:562-599) and the reactive branch
+// of agent_update (:213-224): every deciding agent acts alone on the next entry of its preset route,
+// max_waiting_time = 100, cut-off at t = 200, tasks become visible in batches of 20 every 10 time units
+// (capped at 100) when reactive.  This is the deterministic known-answer path of the reference (the
+// CTAS-D routes reproduce testSet_20A_50T_CONDET/metrics/metrics.csv:2) and BASELINE config 5.
+//
+// One wavefront per env, the whole episode in one launch, state in LDS only (instance fields are read from
+// the env record that dcm_load_instances filled).  Unlike RL mode a task may collect more members than its
+// requirement, so member slots are sized by `member_cap` (<= 32) and walked with runtime loops.
+#include "common.hpp"
+
+using namespace dcm;
+
+namespace {
+
+constexpr int MR_MAX = 32;
+constexpr uint32_t R_TYPE_ERROR = DCM_FLAG_TYPE_ERROR;
+
+// LDS layout of the replay state
+struct RLay {
+    int A, T, MR;
+    __device__ uint32_t ax() const { return 0; }
+    __device__ uint32_t ay() const { return 8 * A; }
+    __device__ uint32_t arr() const { return 16 * A; }
+    __device__ uint32_t nd() const { return 24 * A; }
+    __device__ uint32_t tdist() const { return 32 * A; }
+    __device__ uint32_t aw() const { return 40 * A; }
+    __device__ uint32_t cur() const { return 48 * A; }
+    __device__ uint32_t ainfo() const { return 52 * A; }
+    __device__ uint32_t phead() const { return 56 * A; }
+    __device__ uint32_t plen() const { return 60 * A; }
+    __device__ uint32_t tb() const { return 64 * A; }
+    __device__ uint32_t ts() const { return tb(); }
+    __device__ uint32_t tf() const { return tb() + 8 * T; }
+    __device__ uint32_t tx() const { return tb() + 16 * T; }
+    __device__ uint32_t ty() const { return tb() + 24 * T; }
+    __device__ uint32_t tdur() const { return tb() + 32 * T; }
+    __device__ uint32_t tw() const { return tb() + 40 * T; }
+    __device__ uint32_t marr() const { return tb() + 48 * T; }             // f64[MR][T]
+    __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
+    __device__ uint32_t tnab() const { return tinfo() + 4 * T; }           // u32[T]
+    __device__ uint32_t mid() const { return tnab() + 4 * T; }             // u8[MR][T]
+};
+__host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
+    return align16((uint32_t)(64 * A + 48 * T + 8 * MR * T + 8 * T + MR * T));
+}
+
+struct RP {
+    double mwt;     // 100, env/task_env.py:564
+    double cutoff;  // 200, :565
+    int reactive;
+};
+
+// Python float floor division (now // 10, env/task_env.py:567)
+__device__ double py_floordiv(double vx, double wx) {
+    double mod = fmod(vx, wx), div = (vx - mod) / wx, fl;
+    if (mod != 0.0) { if ((wx < 0) != (mod < 0)) { mod += wx; div -= 1.0; } }
+    if (div != 0.0) { fl = floor(div); if (div - fl > 0.5) fl += 1.0; } else fl = copysign(0.0, vx / wx);
+    return fl;
+}
+
+struct Rep {
+    int A, T, MR;
+    unsigned char* b;
+    RLay L;
+    __device__ double* ax() const { return (double*)(b + L.ax()); }
+    __device__ double* ay() const { return (double*)(b + L.ay()); }
+    __device__ double* arr() const { return (double*)(b + L.arr()); }
+    __device__ double* nd() const { return (double*)(b + L.nd()); }
+    __device__ double* tdist() const { return (double*)(b + L.tdist()); }
+    __device__ double* aw() const { return (double*)(b + L.aw()); }
+    __device__ int32_t* cur() const { return (int32_t*)(b + L.cur()); }
+    __device__ uint32_t* ainfo() const { return (uint32_t*)(b + L.ainfo()); }
+    __device__ int32_t* phead() const { return (int32_t*)(b + L.phead()); }
+    __device__ int32_t* plen() const { return (int32_t*)(b + L.plen()); }
+    __device__ double* ts() const { return (double*)(b + L.ts()); }
+    __device__ double* tf() const { return (double*)(b + L.tf()); }
+    __device__ double* tx() const { return (double*)(b + L.tx()); }
+    __device__ double* ty() const { return (double*)(b + L.ty()); }
+    __device__ double* tdur() const { return (double*)(b + L.tdur()); }
+    __device__ double* tw() const { return (double*)(b + L.tw()); }
+    __device__ double* marr() const { return (double*)(b + L.marr()); }
+    __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
+    __device__ uint32_t* tnab() const { return (uint32_t*)(b + L.tnab()); }
+    __device__ uint8_t* mid() const { return (uint8_t*)(b + L.mid()); }
+
+    // tinfo[t]: bits 0-7 requirements, 8-15 status (int8), 16-23 len(members), 24 feasible, 25 finished
+
+    // env/task_env.py:245-281 with up to MR members per task
+    __device__ void task_update(double now, double mwt, int lane, uint32_t& flags) const {
+        bool allf = true;
+        for (int t = lane; t < T; t += WAVE) {
+            uint32_t info = tinfo()[t];
+            if (!(info & T_FEAS)) {                                          // :249
+                const int req = info & 0xFF;
+                const int n = (info >> 16) & 0xFF;                           // :250
+                const int status = req - n;                                  // :252
+                uint32_t keep = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                bool changed = false;
+                if (status <= 0) {                                           // :254
+                    double mx = marr()[t], mn = mx;
+                    for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                    if (mx - mn <= mwt) {                                    // :255
+                        ts()[t] = mx; tf()[t] = mx + tdur()[t]; info |= T_FEAS;   // :256-258
+                    } else {
+                        const double thr = mx - mwt;                         // :262
+                        for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }
+                    }
+                } else {
+                    bool skip = false;                                       // :268-271 (quirk Q1)
+                    for (int j = 0; j < n; j++) {
+                        if (skip) { skip = false; continue; }
+                        if (now - marr()[j * T + t] >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
+                    }
+                }
+                int nn = n;
+                if (changed) {
+                    int k = 0;
+                    for (int j = 0; j < n; j++) {
+                        const uint32_t id = mid()[j * T + t];
+                        if (keep & (1u << j)) {
+                            if (k != j) { mid()[k * T + t] = (uint8_t)id; marr()[k * T + t] = marr()[j * T + t]; }
+                            k++;
+                        } else {
+                            atomicAdd(&ainfo()[id], 1u << 16);               // abandoned_agent.append :265/:271
+                            if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
+                        }
+                    }
+                    tnab()[t] += (uint32_t)(n - k);
+                    nn = k;
+                }
+                info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
+            } else if (now >= tf()[t]) {
+                info |= T_FIN;                                               // :273-274
+            }
+            tinfo()[t] = info;
+            allf = allf && (info & T_FEAS);
+        }
+        const bool all_feasible = __all(allf);
+        WSYNC();
+        for (int a = lane; a < A; a += WAVE) {                               // depot :277-280
+            const uint32_t ai = ainfo()[a];
+            if ((ai & A_INDEPOT) && all_feasible && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+        }
+    }
+
+    // env/task_env.py:207-243 including the reactive depot branch :213-224
+    __device__ void agent_update(double now, double mwt, int reactive, int visible, int lane, uint32_t& flags) const {
+        bool allf_vis = true;
+        if (reactive) {                                                      // :214 all(feasible[:visible_length])
+            const int lim = visible < T ? visible : T;
+            for (int t = lane; t < lim; t += WAVE) allf_vis = allf_vis && (tinfo()[t] & T_FEAS);
+            allf_vis = __all(allf_vis);
+        }
+        bool terr = false;
+        for (int a = lane; a < A; a += WAVE) {
+            const int c = cur()[a];
+            if (c == -2) continue;                                           // :209
+            uint32_t ai = ainfo()[a];
+            if (c == -1) {                                                   // :212
+                if (!reactive || allf_vis) { nd()[a] = __builtin_nan(""); continue; }   // :215,:226
+                const int len = plen()[a], head = phead()[a];
+                if (len >= 0 && head >= len) { nd()[a] = __builtin_nan(""); continue; }  // :217-218
+                if (len < 0) { terr = true; continue; }                      // :220 TypeError in the reference
+                // next preset action is read by the caller-provided pointer; stored in aw() scratch by the kernel
+                const int next_action = (int)aw()[a];                        // staged by stage_next()
+                int q = (next_action - 1) / 20;                              // :221 python floor division
+                if ((next_action - 1) % 20 != 0 && (next_action - 1) < 0) q--;
+                const double ndt = (double)(q * 10);
+                double v = arr()[a];                                         // :222 np.max([...])
+                v = ndt > v ? ndt : v;
+                v = now > v ? now : v;
+                nd()[a] = v;
+                ainfo()[a] = ai & ~A_INDEPOT;                                // :223-224 depot['members'].remove
+                continue;
+            }
+            const uint32_t info = tinfo()[c];                                // :228
+            const bool member = (info & T_FEAS) && (ai & A_MEMBER);          // :229-230
+            if (member) {
+                nd()[a] = tf()[c];                                           // :231
+                if (now >= ts()[c]) ai |= A_ASSIGNED;                        // :232-233
+            } else {
+                nd()[a] = arr()[a] + mwt;                                    // :235/:238
+                ai &= ~A_ASSIGNED;                                           // :236/:240
+            }
+            ainfo()[a] = ai;
+        }
+        if (__any(terr)) flags |= R_TYPE_ERROR;
+    }
+};
+
+__global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, const unsigned char* state,
+                                                const int32_t* routes, const int32_t* route_len, int route_cap,
+                                                double* summary, int64_t* steps_out, uint32_t* flags_out,
+                                                uint8_t* finished, double* time_start, double* time_finish,
+                                                double* task_wait, int32_t* n_members, double* agent_wait,
+                                                double* travel_dist, uint8_t* returned) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const Lay EL{A, T};
+    const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
+    Rep R{A, T, MR, smem, RLay{A, T, MR}};
+    const Hdr* gh = (const Hdr*)rec;
+    const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
+    const int32_t* my_routes = routes + (size_t)e * A * route_cap;
+    // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance
+    {
+        const double* gtx = (const double*)(rec + EL.tx());
+        const double* gty = (const double*)(rec + EL.ty());
+        const double* gtd = (const double*)(rec + EL.tdur());
+        const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
+        for (int t = lane; t < T; t += WAVE) {
+            R.tx()[t] = gtx[t]; R.ty()[t] = gty[t]; R.tdur()[t] = gtd[t];
+            const uint32_t req = gti[t] & 0xFF;
+            R.tinfo()[t] = req | (req << 8);
+            R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0; R.tw()[t] = 0.0;
+        }
+        for (int a = lane; a < A; a += WAVE) {
+            R.ax()[a] = depot_x; R.ay()[a] = depot_y; R.arr()[a] = 0.0; R.nd()[a] = 0.0; R.tdist()[a] = 0.0;
+            R.aw()[a] = 0.0; R.cur()[a] = -2; R.ainfo()[a] = 0; R.phead()[a] = 0;
+            R.plen()[a] = route_len[(size_t)e * A + a];                      // pre_set_route :595-599 (-1 = None)
+        }
+    }
+    double now = 0.0;
+    uint32_t flags = 0;
+    bool finished_flag = false;
+    int visible = 0, guard = 0;
+    int64_t steps = 0;
+    const double mwt = P.mwt;                                                // :564
+    // Guard (not in the reference): with reactive planning a depot agent whose next task id is beyond the hard
+    // visibility cap of 100 re-decides at the same time forever (env/task_env.py:220-222,578-584); stop such envs.
+    const int64_t step_cap = 64 * (int64_t)(A + T) + 4096;
+    WSYNC();
+    // stage the next preset action of every agent into aw() (scratch until the terminal metrics)
+    auto stage_next = [&]() {
+        for (int a = lane; a < A; a += WAVE) {
+            const int len = R.plen()[a], head = R.phead()[a];
+            R.aw()[a] = (len > 0 && head < len) ? (double)my_routes[(size_t)a * route_cap + head] : 0.0;
+        }
+    };
+    while (!finished_flag && now < P.cutoff) {                               // :565
+        if (P.reactive) {                                                    // :566-567
+            double v = py_floordiv(now, 10.0) * 20.0 + 20.0;
+            v = v < 20.0 ? 20.0 : v; v = v > 100.0 ? 100.0 : v;
+            visible = (int)v;
+        }
+        // next_decision :283-289
+        double lmin = __builtin_nan(""), lmax = 0.0;
+        for (int a = lane; a < A; a += WAVE) {
+            lmin = fmin(lmin, R.nd()[a]);
+            const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
+            lmax = av > lmax ? av : lmax;
+        }
+        const double tmin = wave_nanmin(lmin);
+        const bool any = (tmin == tmin);
+        now = any ? tmin : wave_nanmax(lmax);                                // :569
+        // deciding set (exact ==), fixed before the updates like the reference's `decision_agents`
+        uint64_t dm[AW_MAX];
+#pragma unroll
+        for (int i = 0; i < AW_MAX; i++) {
+            const int a = i * 64 + lane;
+            dm[i] = __ballot(any && a < A && R.nd()[a < A ? a : 0] == tmin);
+        }
+        stage_next();
+        WSYNC();
+        R.task_update(now, mwt, lane, flags);                                // :570
+        WSYNC();
+        R.agent_update(now, mwt, P.reactive, visible, lane, flags);          // :571
+        WSYNC();
+        if (flags & R_TYPE_ERROR) break;
+        if (!any) { if (++guard > 8) { flags |= DCM_FLAG_TRUNCATED; break; } } else guard = 0;
+#pragma unroll
+        for (int i = 0; i < AW_MAX; i++) {
+            uint64_t m = dm[i];
+            while (m) {                                                      // :572 for agent in decision_agents
+                const int a = i * 64 + __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const int len = uni(R.plen()[a]), head = uni(R.phead()[a]);
+                int action;
+                if (len < 0 || head >= len) action = 0;                      // :573-577
+                else {
+                    const int nxt = my_routes[(size_t)a * route_cap + head];
+                    if (P.reactive && nxt > visible) action = 0;             // :578-584
+                    else { action = nxt; if (lane == 0) R.phead()[a] = head + 1; }   // :585 pop(0)
+                }
+                if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
+                // agent_step :300-324
+                const double tx_ = action ? uni(R.tx()[action - 1]) : depot_x, ty_ = action ? uni(R.ty()[action - 1]) : depot_y;
+                if (lane == 0) {
+                    const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
+                    const double arrival = now + d / 0.2;                    // :315,:318
+                    R.tdist()[a] += d;                                       // :317
+                    R.arr()[a] = arrival;
+                    R.ax()[a] = tx_; R.ay()[a] = ty_;                        // :320
+                    R.cur()[a] = action - 1;                                 // :314
+                    uint32_t ai = R.ainfo()[a] & ~A_MEMBER;
+                    if (action == 0) ai |= A_INDEPOT;                        // :321-322
+                    else {
+                        const int k = action - 1;
+                        uint32_t info = R.tinfo()[k];
+                        int n = (info >> 16) & 0xFF, pos = -1;
+                        for (int j = 0; j < n; j++) if (R.mid()[j * T + k] == a) pos = j;
+                        if (pos < 0) {
+                            if (n >= MR) flags |= DCM_FLAG_OVERFLOW;
+                            else { pos = n++; R.mid()[pos * T + k] = (uint8_t)a; }
+                        }
+                        if (pos >= 0) { R.marr()[pos * T + k] = arrival; ai |= A_MEMBER; }
+                        R.tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16);
+                    }
+                    R.ainfo()[a] = ai;
+                }
+                flags |= (uint32_t)__builtin_amdgcn_readlane((int)flags, 0);
+                if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
+                WSYNC();
+                stage_next();
+                WSYNC();
+                R.task_update(now, mwt, lane, flags);                        // :575/:582/:586
+                WSYNC();
+                R.agent_update(now, mwt, P.reactive, visible, lane, flags);  // :576/:583/:587
+                WSYNC();
+                if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
+            }
+            if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
+        }
+        if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
+        // check_finished :366-373,:588
+        double l2 = __builtin_nan(""), m2 = 0.0;
+        bool allret = true;
+        for (int a = lane; a < A; a += WAVE) {
+            l2 = fmin(l2, R.nd()[a]);
+            const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
+            m2 = av > m2 ? av : m2;
+            allret = allret && (R.ainfo()[a] & A_RETURNED);
+        }
+        const double t2 = wave_nanmin(l2);
+        if (!(t2 == t2)) {
+            now = wave_nanmax(m2);
+            bool allfin = true;
+            for (int t = lane; t < T; t += WAVE) allfin = allfin && (R.tinfo()[t] & T_FIN);
+            finished_flag = __all(allret) && __all(allfin);
+        } else finished_flag = false;
+    }
+    WSYNC();
+    // ---- get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
+    for (int t = lane; t < T; t += WAVE) {
+        const uint32_t info = R.tinfo()[t];
+        const int n = (info >> 16) & 0xFF;
+        const double ab = (double)R.tnab()[t] * mwt;
+        double s = 0.0;
+        if (n != 0) {
+            double mx = R.marr()[t];
+            for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
+            const bool feas = info & T_FEAS;
+            auto term = [&](int j) { const double v = R.marr()[j * T + t]; return feas ? (mx - v) : (now - v); };
+            if (n < 8) { for (int j = 0; j < n; j++) s += term(j); }
+            else {
+                double r[8];
+                for (int j = 0; j < 8; j++) r[j] = term(j);
+                int i;
+                for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += term(i + j);
+                s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < n; i++) s += term(i);
+            }
+        }
+        R.tw()[t] = s + ab;
+    }
+    for (int a = lane; a < A; a += WAVE) {
+        double s = 0.0;
+        for (int t = 0; t < T; t++) {
+            const uint32_t info = R.tinfo()[t];
+            const int n = (info >> 16) & 0xFF;
+            int pos = -1;
+            for (int j = 0; j < n; j++) if (R.mid()[j * T + t] == a) pos = j;
+            if (pos < 0) continue;
+            const double mine = R.marr()[pos * T + t];
+            if (info & T_FEAS) {
+                double mx = R.marr()[t];
+                for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
+                s += mx - mine;                                              // :360
+            } else { const double w = now - mine; s += (w > 0.0) ? w : 0.0; }   // :362
+        }
+        s += (double)(R.ainfo()[a] >> 16) * mwt;                             // :363-364 (count * mwt, DESIGN.md deviation)
+        R.aw()[a] = s;
+    }
+    WSYNC();
+    int nfin = 0;
+    for (int t0 = 0; t0 < T; t0 += WAVE) {
+        const int t = t0 + lane;
+        nfin += __popcll(__ballot(t < T && (R.tinfo()[t < T ? t : 0] & T_FIN)));
+    }
+    const double Td = (double)T, Ad = (double)A;
+    const double m2 = psum<3>(R.ts(), T) / Td, m3 = psum<3>(R.aw(), A) / Ad, m4 = psum<3>(R.tdist(), A),
+                 m5 = psum<3>(R.tw(), T) / Td;
+    if (lane == 0) {
+        double* row = summary + (size_t)e * 8;
+        row[0] = -now; row[1] = (double)nfin; row[2] = (double)nfin / Td; row[3] = now;
+        row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
+        if (steps_out) steps_out[e] = steps;
+        if (flags_out) flags_out[e] = flags | DCM_FLAG_DONE | (finished_flag ? DCM_FLAG_FINISHED : 0u);
+    }
+    for (int t = lane; t < T; t += WAVE) {
+        const size_t o = (size_t)e * T + t;
+        const uint32_t info = R.tinfo()[t];
+        if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
+        if (time_start) time_start[o] = R.ts()[t];
+        if (time_finish) time_finish[o] = R.tf()[t];
+        if (task_wait) task_wait[o] = R.tw()[t];
+        if (n_members) n_members[o] = (info >> 16) & 0xFF;
+    }
+    for (int a = lane; a < A; a += WAVE) {
+        const size_t o = (size_t)e * A + a;
+        if (agent_wait) agent_wait[o] = R.aw()[a];
+        if (travel_dist) travel_dist[o] = R.tdist()[a];
+        if (returned) returned[o] = (R.ainfo()[a] & A_RETURNED) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_len, int32_t route_cap, int32_t member_cap,
+                    void* stream) {
+    CHECK_ENV(env);
+    if (!routes || !route_len || route_cap < 1) return fail(DCM_ERR_INVALID, "dcm_load_routes: bad argument");
+    if (member_cap < 1 || member_cap > MR_MAX) return fail(DCM_ERR_INVALID, "dcm_load_routes: member_cap must be in 1..32");
+    if (replay_lds_bytes(env->L.A, env->L.T, member_cap) > 160 * 1024)
+        return fail(DCM_ERR_INVALID, "dcm_load_routes: replay state does not fit the 160 KiB LDS; lower member_cap");
+    HIP_TRY(hipSetDevice(env->p.device));
+    const size_t nr = (size_t)env->p.n_envs * env->L.A * route_cap, nl = (size_t)env->p.n_envs * env->L.A;
+    if (env->routes) { (void)hipFree(env->routes); env->routes = nullptr; }
+    if (env->route_len) { (void)hipFree(env->route_len); env->route_len = nullptr; }
+    HIP_TRY(hipMalloc((void**)&env->routes, nr * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&env->route_len, nl * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(env->routes, routes, nr * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(env->route_len, route_len, nl * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    env->route_cap = route_cap;
+    env->member_cap = member_cap;
+    return DCM_OK;
+}
+
+int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint32_t* flags_out, uint8_t* finished,
+                       double* time_start, double* time_finish, double* task_wait, int32_t* n_members,
+                       double* agent_wait, double* travel_dist, uint8_t* returned, void* stream) {
+    CHECK_ENV(env);
+    if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_instances first");
+    if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
+    const uint32_t lds = replay_lds_bytes(env->L.A, env->L.T, env->member_cap);
+    (void)hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    RP P{100.0, 200.0, reactive ? 1 : 0};  // env/task_env.py:564-565
+    hipLaunchKernelGGL(k_replay, GRID(env), lds, (hipStream_t)stream, env->L.A, env->L.T, env->member_cap, P, env->state,
+                       env->routes, env->route_len, env->route_cap, env->summary, steps_out, flags_out, finished, time_start,
+                       time_finish, task_wait, n_members, agent_wait, travel_dist, returned);
+    LAUNCH_OK();
+    return DCM_OK;
+}
+
+}  // extern "C"

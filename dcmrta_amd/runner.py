@@ -1,0 +1,151 @@
+"""BatchedRunner -- the rollout side of runner.py / worker.py for a whole batch of envs on one GPU.
+
+What one Ray actor of the reference does for ONE env per `job` (runner.py:58-71 -> worker.py:41-112) this class does
+for B envs at once: a sampled episode per env recorded as the 9-slot experience the learner consumes
+(driver.py:135-164), the greedy self-critic twin rollout on the same instances (worker.py:89-92,200-235), the
+advantage (worker.py:91-101, GAMMA=1 so every decision of an episode carries the episode advantage) and the six
+perf metrics (worker.py:103-108).  The env work is the HIP path (BatchedTaskEnv); the policy is whatever module the
+caller supplies (`net_factory`, e.g. the reference's own AttentionNet) -- by default the stand-in of dcmrta_amd.policy.
+
+job() keeps the reference signature and return shape:
+    jobResults : list of 9 sequences; torch.stack(jobResults[k]) gives (N,A,6), (N,T+1,5), (N,1) int64, (N,T+1) bool,
+                 (N,1), (N,1,1) int64, (N,1) -- N = decisions of all B episodes, episode-major order
+    metrics    : dict with success_rate, makespan, time_cost, waiting_time, travel_dist, efficiency (means over the batch)
+    info       : {"id", "episode_number"}
+"""
+import numpy as np
+import torch
+
+from .batched_env import BatchedTaskEnv
+from .choice import env_seeds
+from .instances import generate_batch
+
+METRIC_KEYS = ("success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency")
+
+
+class BatchedRunner:
+    def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=1024):
+        self.metaAgentID = metaAgentID
+        self.device = torch.device(device)
+        self.B = int(n_envs)
+        self.base_seed = int(base_seed)
+        self.max_steps = int(max_steps)
+        if net_factory is None:
+            from .policy import AttentionNet
+            net_factory = lambda: AttentionNet(6, 5, 128)  # AGENT_INPUT_DIM, TASK_INPUT_DIM, EMBEDDING_DIM (parameters.py:29-31)
+        self.localNetwork = net_factory().to(self.device)     # runner.py:18-19
+        self.localBaseline = net_factory().to(self.device)    # runner.py:20-21
+        self._env = None
+        self.timing = {}
+
+    # ------------------------------------------------------------------ weights (runner.py:23-30)
+    def get_weights(self):
+        return self.localNetwork.state_dict()
+
+    def set_weights(self, weights):
+        self.localNetwork.load_state_dict(weights)
+
+    def set_baseline_weights(self, weights):
+        self.localBaseline.load_state_dict(weights)
+
+    # ------------------------------------------------------------------ env management
+    def _get_env(self, A, T):
+        if self._env is None or (self._env.A, self._env.T) != (A, T):
+            if self._env is not None:
+                self._env.close()
+            self._env = BatchedTaskEnv(self.B, A, T, device=str(self.device))
+        return self._env
+
+    # ------------------------------------------------------------------ one batched episode (worker.py:45-87)
+    @torch.no_grad()
+    def rollout(self, net, env, seeds, greedy, record):
+        B, A, T, dev = env.B, env.A, env.T, env.device
+        obs = env.reset(seeds)
+        S = self.max_steps
+        rec = None
+        if record:
+            rec = dict(agents=torch.empty((S, B, A, 6), dtype=torch.float32, device=dev),
+                       tasks=torch.empty((S, B, T + 1, 5), dtype=torch.float32, device=dev),
+                       mask=torch.empty((S, B, T + 1), dtype=torch.bool, device=dev),
+                       action=torch.zeros((S, B), dtype=torch.int64, device=dev),
+                       leader=torch.zeros((S, B), dtype=torch.int64, device=dev),
+                       active=torch.zeros((S, B), dtype=torch.bool, device=dev))
+        s = 0
+        while True:
+            if not bool(obs.active.any()):       # worker.py:45 for every env of the batch
+                break
+            if s >= S:
+                raise RuntimeError("episode longer than max_steps")
+            logp = net(obs.tasks, obs.agents, obs.mask)                          # worker.py:69
+            if greedy:
+                action = torch.argmax(logp, dim=1)                               # worker.py:228
+            else:
+                action = torch.distributions.Categorical(logits=logp).sample()  # worker.py:70 (probs = logp.exp())
+            if record:
+                rec["agents"][s].copy_(obs.agents); rec["tasks"][s].copy_(obs.tasks); rec["mask"][s].copy_(obs.mask)
+                rec["action"][s].copy_(action); rec["leader"][s].copy_(obs.leader); rec["active"][s].copy_(obs.active)
+            obs = env.step(action.to(torch.int32))                               # worker.py:73-76,85
+            s += 1
+        summary = env.summary()                                                  # worker.py:87,103-108
+        return summary, rec, s
+
+    def _experience(self, rec, n_steps, reward, advantage, as_lists):
+        """9-slot buffer of worker.py:42,77-83,91-101 for all episodes, episode-major."""
+        act = rec["active"][:n_steps].t()                                        # [B,S]
+        def pick(x):
+            return x[:n_steps].transpose(0, 1)[act]                              # [N,...] env-major, step order
+        agents, tasks, mask = pick(rec["agents"]), pick(rec["tasks"]), pick(rec["mask"])
+        action = pick(rec["action"]).unsqueeze(1)                                # (N,1) int64, slot 2
+        agent_id = pick(rec["leader"]).view(-1, 1, 1)                            # (N,1,1) int64, slot 5
+        counts = act.sum(1)                                                      # decisions per episode
+        env_of = torch.repeat_interleave(torch.arange(act.shape[0], device=act.device), counts)
+        last = torch.cumsum(counts, 0) - 1
+        rew = torch.zeros((agents.shape[0], 1), dtype=torch.float32, device=agents.device)
+        rew[last[counts > 0], 0] = reward[counts > 0].to(torch.float32)          # slot 4: 0 except the last decision (:81,:91)
+        adv = advantage.to(torch.float32)[env_of].unsqueeze(1)                   # slot 6 (:92-101, GAMMA = 1)
+        slots = [agents, tasks, action, mask, rew, agent_id, adv, [], []]
+        if as_lists:
+            slots = [list(x.unbind(0)) if isinstance(x, torch.Tensor) else x for x in slots]
+        return slots
+
+    # ------------------------------------------------------------------ runner.py:58-71
+    def job(self, global_weights, baseline_weights, episodeNumber, agents_num, tasks_num, as_lists=False):
+        self.set_weights(global_weights)
+        self.set_baseline_weights(baseline_weights)
+        A = int(agents_num[1] if isinstance(agents_num, tuple) else agents_num)
+        T = int(tasks_num[1] if isinstance(tasks_num, tuple) else tasks_num)
+        env = self._get_env(A, T)
+        first = int(episodeNumber) * self.B
+        inst = generate_batch(self.B, A, T, base_seed=self.base_seed, first=first)   # worker.py:32
+        env.load_instances(**inst)
+        seeds = env_seeds(self.base_seed, first, self.B)
+        summary, rec, n_steps = self.rollout(self.localNetwork, env, seeds, greedy=False, record=True)   # run_episode
+        greedy_summary, _, _ = self.rollout(self.localNetwork, env, seeds, greedy=True, record=False)    # baseline_test :89
+        reward, greedy_reward = summary[:, 0], greedy_summary[:, 0]
+        advantage = reward - greedy_reward                                         # worker.py:92
+        jobResults = self._experience(rec, n_steps, reward, advantage, as_lists)
+        m = summary[:, 2:8].mean(0).cpu().numpy()
+        metrics = {k: float(m[i]) for i, k in enumerate(METRIC_KEYS)}
+        info = {"id": self.metaAgentID, "episode_number": episodeNumber}
+        self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps)
+        return jobResults, metrics, info
+
+    # ------------------------------------------------------------------ runner.py:45-49 (greedy evaluation)
+    def testing(self, agents_range=20, tasks_range=50, seed=None, seeds=None):
+        """Greedy reward(s) of the local network on seeded instances; seed -> float, seeds -> numpy array."""
+        A = int(agents_range[1] if isinstance(agents_range, tuple) else agents_range)
+        T = int(tasks_range[1] if isinstance(tasks_range, tuple) else tasks_range)
+        ss = [seed if seed is not None else 0] if seeds is None else list(seeds)
+        out = []
+        env = self._get_env(A, T)
+        for i in range(0, len(ss), self.B):
+            chunk = ss[i:i + self.B]
+            pad = chunk + [chunk[-1]] * (self.B - len(chunk))
+            from .instances import generate_instance
+            insts = [generate_instance(A, T, s) for s in pad]
+            env.load_instances(np.stack([x["depot"] for x in insts]), np.stack([x["task_xy"] for x in insts]),
+                               np.stack([x["req"] for x in insts]), np.stack([x["dur"] for x in insts]))
+            cs = np.array([env_seeds(self.base_seed, int(s), 1)[0] for s in pad], dtype=np.uint64)
+            summary, _, _ = self.rollout(self.localNetwork, env, cs, greedy=True, record=False)
+            out.extend(summary[:len(chunk), 0].cpu().numpy().tolist())
+        return out[0] if seeds is None else np.array(out)

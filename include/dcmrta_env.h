@@ -56,6 +56,7 @@ typedef enum {
 #define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T] */
 #define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members (masked action chosen) */
 #define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
+#define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 
 typedef struct {
     int32_t n_envs;             /* B */
@@ -147,6 +148,22 @@ int dcm_restore_state(dcm_env *env, const void *src, void *stream);
  * known-answer test of the fp64 sqrt/divide path: dist_out[n], time_out[n] (nullable). */
 int dcm_distance(const double *ax, const double *ay, const double *bx, const double *by, double *dist_out,
                  double *time_out, int64_t n, void *stream);
+
+/* pre_set_route (env/task_env.py:595-599) for every agent of every env:
+ * routes[B,A,route_cap] i32 actions in visiting order (0 = depot, k = task k-1; what baselines/CTAS-D.py:41-45 passes),
+ * route_len[B,A] i32 (-1 = pre_set_route stays None, 0 = empty list).  member_cap (1..32) sizes the per-task member
+ * slots of replay mode, where a task may collect more agents than it requires. Arrays are copied. */
+int dcm_load_routes(dcm_env *env, const int32_t *routes, const int32_t *route_len, int32_t route_cap,
+                    int32_t member_cap, void *stream);
+
+/* execute_by_route (env/task_env.py:562-593; max_waiting_time 100, cut-off 200) followed by get_episode_reward
+ * (:420-425), whole episode in one launch.  reactive != 0 enables dynamic task visibility (:566-567,:578-584 and the
+ * depot branch of agent_update :213-224).  Results: dcm_summary rows + the optional arrays
+ * steps_out i64[B] (agent_step calls), flags_out u32[B] (DCM_FLAG_*), finished u8[B,T], time_start/time_finish/
+ * task_wait f64[B,T], n_members i32[B,T], agent_wait/travel_dist f64[B,A], returned u8[B,A]. */
+int dcm_execute_routes(dcm_env *env, int32_t reactive, int64_t *steps_out, uint32_t *flags_out, uint8_t *finished,
+                       double *time_start, double *time_finish, double *task_wait, int32_t *n_members,
+                       double *agent_wait, double *travel_dist, uint8_t *returned, void *stream);
 
 /* bytes of canonical state per env: S = 64 + 48*A + 96*T */
 int dcm_record_bytes(dcm_env *env, size_t *bytes_out);

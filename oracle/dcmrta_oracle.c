@@ -592,6 +592,7 @@ int orc_execute_by_route(orc_env *e, int reactive) {
     e->reactive = reactive;
     e->mwt = 100.0;                                                         /* :564 */
     int guard = 0;
+    long steps = 0, step_cap = 64L * (e->A + e->T) + 4096; /* guard shared with the HIP kernel (not in the reference) */
     while (!e->finished && e->now < 200.0) {                                /* :565 */
         if (e->reactive) {                                                  /* :566-567 */
             double v = py_floordiv(e->now, 10.0) * 20.0 + 20.0;
@@ -614,6 +615,7 @@ int orc_execute_by_route(orc_env *e, int reactive) {
             else if (e->reactive && e->preset[a].v[e->preset_head[a]] > e->visible_length) action = 0; /* :578-584 */
             else action = e->preset[a].v[e->preset_head[a]++];              /* :585 pop(0) */
             orc_agent_step(e, a, action);
+            if (++steps > step_cap) { e->truncated = 1; free(ids); return 0; }
             orc_task_update(e);                                             /* :575/:582/:586 */
             orc_agent_update(e);                                            /* :576/:583/:587 */
             if (e->type_error) { free(ids); return -2; }

@@ -1,0 +1,88 @@
+"""-m gpu: route replay (execute_by_route, env/task_env.py:562-593) on the device.
+
+ * the reference-published known answer: CTAS-D routes -> metrics/metrics.csv:2 (via the committed G3 outputs)
+ * dynamic task visibility (reactive_planning) incl. the 4 instances where the reference raises TypeError
+ * BASELINE config-5 size (100A/500T) against the oracle on synthetic routes"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+KEYS_EXACT = ("finished", "time_start", "time_finish", "task_wait", "n_members", "travel_dist", "returned")
+
+
+def _check(out, b, ref, name):
+    for k in KEYS_EXACT:
+        got = out[k][b].cpu().numpy()
+        assert np.array_equal(got.astype(np.asarray(ref[k]).dtype), ref[k]), (name, k)
+    np.testing.assert_allclose(out["agent_wait"][b].cpu().numpy(), ref["agent_wait"], rtol=1e-12, atol=1e-12)
+    sm = out["summary"][b].cpu().numpy()
+    m = ref["metrics"]
+    assert sm[3] == ref["makespan"] and sm[0] == -ref["makespan"], name
+    for i in (0, 1, 2, 4, 5):
+        assert sm[2 + i] == m[i], (name, i)
+    np.testing.assert_allclose(sm[5], m[3], rtol=1e-12)
+
+
+@pytest.mark.parametrize("reactive,fixture", [(False, "ctasd_replay"), (True, "reactive_replay")])
+def test_ctasd_routes_known_answer(gpu_device, golden_dir, reactive, fixture):
+    from dcmrta_amd import _lib
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import load_instances_npz, load_routes_json
+    inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    routes = load_routes_json(os.path.join(golden_dir, "ctasd_routes.json"))
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    env = BatchedTaskEnv(50, A, 50, device=gpu_device)
+    env.load_instances(**inst)
+    # baselines/CTAS-D.py:41-45: a vehicle whose node list is [0] keeps pre_set_route None; otherwise nodes[1:]
+    rl = [[(None if r == [0] else r[1:]) for r in routes[i]] + [None] * (A - len(routes[i])) for i in range(50)]
+    env.load_routes(rl)
+    out = env.execute_routes(reactive=reactive)
+    flags = out["flags"].cpu().numpy()
+    idx, raised = list(g["idx"]), list(g["raised"])
+    for i in range(50):
+        if i in raised:
+            assert flags[i] & _lib.FLAG_TYPE_ERROR, i      # env/task_env.py:220 raises in the reference
+            continue
+        assert not (flags[i] & (_lib.FLAG_TYPE_ERROR | _lib.FLAG_OVERFLOW | _lib.FLAG_TRUNCATED | _lib.FLAG_BAD_ACTION)), i
+        k = idx.index(i)
+        _check(out, i, {key: g[key][k] for key in g.files if key not in ("idx", "raised")}, f"{fixture}[{i}]")
+    if not reactive:
+        sm = out["summary"].cpu().numpy()
+        # metrics/metrics.csv:2 of the reference: CTAS-D_300s 36.908 makespan, 5.619 waiting, 42.027 travel, 2.248 efficiency
+        assert round(sm[:, 3].mean(), 3) == 36.908 and round(sm[:, 5].mean(), 3) == 5.619
+        assert round(sm[:, 6].mean(), 3) == 42.027 and round(sm[:, 7].mean(), 3) == 2.248
+
+
+def synthetic_routes(req, A, max_task=None):
+    """Every task t is visited by req[t] agents ((7t + j) mod A); each agent visits its tasks in ascending id, then the depot."""
+    T = len(req)
+    r = [[] for _ in range(A)]
+    for t in range(T if max_task is None else min(T, max_task)):
+        for j in range(int(req[t])):
+            r[(7 * t + j) % A].append(t + 1)
+    return [x + [0] for x in r]
+
+
+@pytest.mark.parametrize("A,T,reactive", [(100, 500, False), (100, 500, True), (50, 200, True), (13, 37, False)])
+def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import generate_batch
+    B = 3
+    inst = generate_batch(B, A, T, base_seed=900 + T)
+    rl = [synthetic_routes(inst["req"][b], A, max_task=100 if reactive else None) for b in range(B)]
+    env = BatchedTaskEnv(B, A, T, device=gpu_device)
+    env.load_instances(**inst)
+    env.load_routes(rl, member_cap=8)
+    out = env.execute_routes(reactive=reactive)
+    assert not (out["flags"].cpu().numpy() & 0x7C).any()
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        for a, r in enumerate(rl[b]):
+            o.pre_set_route(r, a)
+        ref = o.execute_by_route(reactive)
+        assert ref["truncated"] == 0
+        _check(out, b, ref, f"{A}A{T}T reactive={reactive} env{b}")

@@ -1,0 +1,63 @@
+"""-m gpu: BatchedRunner.job keeps the reference runner's contract (runner.py:58-71, driver.py:135-176) and its
+experience replays bit-exactly through the oracle (same choices -> same observations)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_job_contract_and_replay(gpu_device, oracle_lib):
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import METRIC_KEYS, BatchedRunner
+    torch.manual_seed(0)
+    B, A, T = 6, 10, 20
+    small = lambda: AttentionNet(6, 5, 32)
+    r = BatchedRunner(metaAgentID=3, n_envs=B, device=gpu_device, net_factory=small, base_seed=11)
+    w = {k: v.clone() for k, v in r.get_weights().items()}
+    jobResults, metrics, info = r.job(w, w, episodeNumber=2, agents_num=A, tasks_num=T, as_lists=True)
+    assert info == {"id": 3, "episode_number": 2} and set(metrics) == set(METRIC_KEYS)
+    assert len(jobResults) == 9 and jobResults[7] == [] and jobResults[8] == []
+    # driver.py:158-164 stacks the per-decision tensors
+    agents, tasks, action, mask = (torch.stack(jobResults[k]) for k in range(4))
+    reward, agent_id, adv = torch.stack(jobResults[4]), torch.stack(jobResults[5]), torch.stack(jobResults[6])
+    N = agents.shape[0]
+    assert agents.shape == (N, A, 6) and tasks.shape == (N, T + 1, 5) and action.shape == (N, 1) and action.dtype == torch.int64
+    assert mask.shape == (N, T + 1) and mask.dtype == torch.bool and reward.shape == (N, 1)
+    assert agent_id.shape == (N, 1, 1) and agent_id.dtype == torch.int64 and adv.shape == (N, 1)
+    logp = r.localNetwork(tasks, agents, mask)
+    assert torch.gather(logp, 1, action).shape == (N, 1)                        # driver.py:176
+    assert not mask.gather(1, action).any()                                      # sampled actions are never masked
+    summary, greedy = r.last["summary"].cpu().numpy(), r.last["greedy_summary"].cpu().numpy()
+    nz = reward[:, 0].nonzero()[:, 0].cpu().numpy()
+    assert len(nz) == B and np.allclose(reward[nz, 0].cpu().numpy(), summary[:, 0].astype(np.float32))  # worker.py:91
+    np.testing.assert_allclose(metrics["makespan"], summary[:, 3].mean())
+    # replay every episode through the oracle with the recorded actions (leaders/followers from the shared protocol)
+    first = 2 * B
+    inst = generate_batch(B, A, T, base_seed=11, first=first)
+    seeds = env_seeds(11, first, B)
+    ends = np.concatenate([[-1], nz])
+    ag, tk, mk, ac, ld = (x.cpu().numpy() for x in (agents, tasks, mask, action[:, 0], agent_id[:, 0, 0]))
+    for b in range(B):
+        lo, hi = ends[b] + 1, ends[b + 1] + 1
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_INJECTED, cap_steps=4096, inj_action=ac[lo:hi].astype(np.int32))
+        assert ref["n_steps"] == hi - lo
+        assert np.array_equal(ref["leader"], ld[lo:hi]) and np.array_equal(ref["agents_obs"], ag[lo:hi])
+        assert np.array_equal(ref["tasks_obs"], tk[lo:hi]) and np.array_equal(ref["mask"], mk[lo:hi].astype(np.uint8))
+        assert ref["reward"] == summary[b, 0]
+        a = adv[lo:hi, 0].cpu().numpy()
+        assert np.allclose(a, np.float32(summary[b, 0] - greedy[b, 0]))          # worker.py:92-101
+
+
+def test_testing_greedy_is_deterministic(gpu_device):
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import BatchedRunner
+    torch.manual_seed(1)
+    r = BatchedRunner(n_envs=4, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32))
+    a = r.testing(8, 12, seeds=range(6))
+    b = r.testing(8, 12, seeds=range(6))
+    assert a.shape == (6,) and np.array_equal(a, b) and (a < 0).all()
+    assert isinstance(r.testing(8, 12, seed=3), float) and r.testing(8, 12, seed=3) == a[3]
