@@ -67,7 +67,7 @@ def synthetic_routes(req, A, max_task=None):
     return [x + [0] for x in r]
 
 
-@pytest.mark.parametrize("A,T,reactive", [(100, 500, False), (100, 500, True), (50, 200, True), (13, 37, False)])
+@pytest.mark.parametrize("A,T,reactive", [(100, 500, False), (100, 500, True), (100, 100, True), (50, 200, True), (13, 37, False)])
 def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
@@ -78,11 +78,14 @@ def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
     env.load_instances(**inst)
     env.load_routes(rl, member_cap=8)
     out = env.execute_routes(reactive=reactive)
-    assert not (out["flags"].cpu().numpy() & 0x7C).any()
+    flags = out["flags"].cpu().numpy()
+    assert not (flags & 0x78).any()
     for b in range(B):
         o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
         for a, r in enumerate(rl[b]):
             o.pre_set_route(r, a)
         ref = o.execute_by_route(reactive)
-        assert ref["truncated"] == 0
+        # With more than 100 tasks the reference's reactive mode never terminates (visibility is hard-capped at 100,
+        # env/task_env.py:567): the zero-decider guard shared by oracle and kernel ends such episodes identically.
+        assert bool(flags[b] & 4) == bool(ref["truncated"]) == (reactive and T > 100)
         _check(out, b, ref, f"{A}A{T}T reactive={reactive} env{b}")
