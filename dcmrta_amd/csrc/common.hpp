@@ -74,7 +74,16 @@ struct KP {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-#define WSYNC() __syncthreads() /* 64-thread workgroup: lowers to a wave barrier + LDS wait */
+// One wavefront == one workgroup: LDS instructions of a wave execute in program order, so cross-lane
+// hand-offs through LDS only need the COMPILER not to reorder across the hand-off.  A wavefront-scope
+// fence does that without the vmcnt(0)/lgkmcnt(0) drain a workgroup-scope __syncthreads() would insert
+// (which made every phase wait for the observation stores to reach memory).
+#define WSYNC()                                               \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 
 // ---------------------------------------------------------------------------------- uniform helpers
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -113,24 +122,36 @@ __device__ __forceinline__ double dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-// NaN-ignoring minimum over the wave (np.nanmin), NaN when every lane is NaN.  fmin/fmax are exact.
+// v_min_f64 / v_max_f64 return the other operand when one is a quiet NaN (IEEE minNum/maxNum) and are
+// exact; written as asm so the compiler does not add a canonicalising v_max_f64 x,x in front of each.
+__device__ __forceinline__ double nanmin2(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double nanmax2(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// NaN-ignoring minimum over the wave (np.nanmin), NaN when every lane is NaN.
 __device__ __forceinline__ double wave_nanmin(double v) {
-    v = fmin(v, dpp_f64<0x111, 0xF>(v));  // row_shr:1
-    v = fmin(v, dpp_f64<0x112, 0xF>(v));  // row_shr:2
-    v = fmin(v, dpp_f64<0x114, 0xF>(v));  // row_shr:4
-    v = fmin(v, dpp_f64<0x118, 0xF>(v));  // row_shr:8  -> lane 15 of each row holds the row minimum
-    v = fmin(v, dpp_f64<0x142, 0xA>(v));  // row_bcast:15 into rows 1,3
-    v = fmin(v, dpp_f64<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave minimum
+    v = nanmin2(v, dpp_f64<0x111, 0xF>(v));  // row_shr:1
+    v = nanmin2(v, dpp_f64<0x112, 0xF>(v));  // row_shr:2
+    v = nanmin2(v, dpp_f64<0x114, 0xF>(v));  // row_shr:4
+    v = nanmin2(v, dpp_f64<0x118, 0xF>(v));  // row_shr:8  -> lane 15 of each row holds the row minimum
+    v = nanmin2(v, dpp_f64<0x142, 0xA>(v));  // row_bcast:15 into rows 1,3
+    v = nanmin2(v, dpp_f64<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave minimum
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_nanmax(double v) {
-    v = fmax(v, dpp_f64<0x111, 0xF>(v));
-    v = fmax(v, dpp_f64<0x112, 0xF>(v));
-    v = fmax(v, dpp_f64<0x114, 0xF>(v));
-    v = fmax(v, dpp_f64<0x118, 0xF>(v));
-    v = fmax(v, dpp_f64<0x142, 0xA>(v));
-    v = fmax(v, dpp_f64<0x143, 0xC>(v));
+    v = nanmax2(v, dpp_f64<0x111, 0xF>(v));
+    v = nanmax2(v, dpp_f64<0x112, 0xF>(v));
+    v = nanmax2(v, dpp_f64<0x114, 0xF>(v));
+    v = nanmax2(v, dpp_f64<0x118, 0xF>(v));
+    v = nanmax2(v, dpp_f64<0x142, 0xA>(v));
+    v = nanmax2(v, dpp_f64<0x143, 0xC>(v));
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
@@ -185,6 +206,13 @@ __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* 
     const uint4* s = (const uint4*)src;
     uint4* d = (uint4*)dst;
     for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = s[i];
+}
+// record HBM -> LDS: streamed once, keep it out of the way of the observation stores in L2
+__device__ __forceinline__ void copy16_in(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* s = (const u32x4*)src;
+    u32x4* d = (u32x4*)dst;
+    for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = __builtin_nontemporal_load(s + i);
 }
 __device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
     if (lane == 0) *(Hdr*)smem = h;

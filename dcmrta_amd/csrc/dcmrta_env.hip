@@ -203,8 +203,7 @@ struct Sim {
 
     // ------------------------------------------------------------------------------ terminal
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
-    __device__ void compute_waits(const Hdr& h, const KP& P, int lane) const {
-        const double now = h.now, mwt = P.mwt;
+    __device__ void compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A();
         for (int t = lane; t < T_; t += WAVE) {
             const uint32_t info = tinfo()[t];
@@ -249,9 +248,10 @@ struct Sim {
     }
 
     // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
-    __device__ __noinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+    // (header fields are passed by value: a by-reference Hdr would force the caller's header into scratch memory)
+    __device__ __noinline__ void terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
         WSYNC();
-        compute_waits(h, P, lane);
+        compute_waits(now, mwt, lane);
         const int T_ = T(), A_ = A();
         int nfin = 0;
         for (int t0 = 0; t0 < T_; t0 += WAVE) {
@@ -265,12 +265,15 @@ struct Sim {
         const double m4 = psum<3>(tdist(), A_);        // np.sum(travel_dist)         :107
         const double m5 = psum<3>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
         if (lane == 0 && row) {
-            row[0] = -h.now;                           // reward, env/task_env.py:424
+            row[0] = -now;                             // reward, env/task_env.py:424
             row[1] = (double)nfin;
             row[2] = (double)nfin / Td;                // success_rate :103
-            row[3] = h.now;                            // makespan :104
+            row[3] = now;                              // makespan :104
             row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
         }
+    }
+    __device__ __forceinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+        terminal_metrics(h.now, P.mwt, lane, row);
         h.flags |= DCM_FLAG_DONE;
         h.episodes += 1;
         h.cur_group = 0;
@@ -291,7 +294,7 @@ struct Sim {
             for (int i = 0; i < NAW; i++) {
                 const int a = i * 64 + lane;
                 ndv[i] = (a < A_) ? nd()[a] : __builtin_nan("");
-                lmin = fmin(lmin, ndv[i]);
+                lmin = nanmin2(lmin, ndv[i]);
             }
             const double tmin = wave_nanmin(lmin);
             const bool any = (tmin == tmin);
@@ -349,12 +352,12 @@ struct Sim {
                     for (;;) {
                         double lx = __builtin_nan("");
 #pragma unroll
-                        for (int i = 0; i < NAW; i++) lx = fmin(lx, todo[i] ? px[i] : __builtin_nan(""));
+                        for (int i = 0; i < NAW; i++) lx = nanmin2(lx, todo[i] ? px[i] : __builtin_nan(""));
                         const double mxv = wave_nanmin(lx);
                         if (!(mxv == mxv)) break;
                         double ly = __builtin_nan("");
 #pragma unroll
-                        for (int i = 0; i < NAW; i++) ly = fmin(ly, (todo[i] && px[i] == mxv) ? py[i] : __builtin_nan(""));
+                        for (int i = 0; i < NAW; i++) ly = nanmin2(ly, (todo[i] && px[i] == mxv) ? py[i] : __builtin_nan(""));
                         const double myv = wave_nanmin(ly);
                         g++;
 #pragma unroll
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
     Sim<CA, CT> S{A, T, smem};
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16(smem, rec, L.rec_bytes(), lane);
+    copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0; h.episodes = 0;
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* s
     Sim<CA, CT> S{A, T, smem};
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16(smem, rec, L.rec_bytes(), lane);
+    copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
     using AMask = typename Sim<CA, CT>::AMask;
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16(smem, rec, L.rec_bytes(), lane);
+    copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     using AMask = typename Sim<CA, CT>::AMask;
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16(smem, rec, L.rec_bytes(), lane);
+    copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
@@ -776,10 +779,10 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<0, 0> S{A, T, smem};
     const Lay L = S.L();
-    copy16(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
+    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    if (sum_wait) S.compute_waits(h, P, lane);
+    if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
     for (int t = lane; t < T; t += WAVE) {
         const size_t o = (size_t)e * T + t;
         const uint32_t info = S.tinfo()[t];
@@ -801,10 +804,10 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigne
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<0, 0> S{A, T, smem};
     const Lay L = S.L();
-    copy16(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
+    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    if (sum_wait) S.compute_waits(h, P, lane);
+    if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
     for (int a = lane; a < A; a += WAVE) {
         const size_t o = (size_t)e * A + a;
         const uint32_t ai = S.ainfo()[a];

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         // next_decision :283-289
         double lmin = __builtin_nan(""), lmax = 0.0;
         for (int a = lane; a < A; a += WAVE) {
-            lmin = fmin(lmin, R.nd()[a]);
+            lmin = nanmin2(lmin, R.nd()[a]);
             const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
             lmax = av > lmax ? av : lmax;
         }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         double l2 = __builtin_nan(""), m2 = 0.0;
         bool allret = true;
         for (int a = lane; a < A; a += WAVE) {
-            l2 = fmin(l2, R.nd()[a]);
+            l2 = nanmin2(l2, R.nd()[a]);
             const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
             m2 = av > m2 ? av : m2;
             allret = allret && (R.ainfo()[a] & A_RETURNED);
