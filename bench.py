@@ -88,7 +88,7 @@ def main():
     K = args.steps
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    counts = []
+    counts, pending = [], []
     ctx.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -96,9 +96,12 @@ def main():
         ev0[k].record()
         steps = env.rollout_random(episodes=1, write_obs=not args.no_obs)
         ev1[k].record()
-        if ctx.world > 1:
-            ctx.all_gather_returns(env.summary()[:, 0])
+        if ctx.world > 1:   # per-episode return exchange; overlaps with the next pass (nothing depends on it)
+            pending.append(ctx.all_gather_returns(env.summary()[:, 0].contiguous(), async_op=True))
         counts.append(steps)
+    for _, work in pending:
+        if work is not None:
+            work.wait()
     torch.cuda.synchronize(dev)
     ctx.barrier()
     elapsed = time.perf_counter() - t0

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench_configs.py -- the BASELINE.json configs other than the headline one (bench.py measures configs[1]).
+
+    python bench_configs.py [--config 1|2l|3|4|5|all]
+
+Prints one JSON line per config (1 GPU; config 4's sharded variant is bench.py --gpus N --envs 8192 --agents 50 --tasks 200):
+  1   1 env, 20A/50T test-set instance 0: oracle (CPU, 1 thread) vs HIP lockstep, per-step latency
+  2l  config 2 through the LOCKSTEP API (dcm_step per decision, uniform-random valid action chosen by a torch op)
+  3   4096 envs 20A/50T, attention policy (stock PyTorch-ROCm) + HIP env step: env-only and end-to-end
+  4   8192 envs/GPU 50A/200T random-policy rollout (the per-GPU shard of 65536 envs over 8 GPUs)
+  5   100A/500T route replay, synthetic routes, with/without dynamic visibility
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
+from dcmrta_amd.choice import env_seeds  # noqa: E402
+from dcmrta_amd.instances import generate_batch, load_instances_npz  # noqa: E402
+from dcmrta_amd.roofline import HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def random_valid_action(mask):
+    """Uniform over unmasked actions, on the device (a torch op standing in for a policy)."""
+    p = (~mask).to(torch.float32)
+    return torch.multinomial(p, 1).squeeze(1).to(torch.int32)
+
+
+def lockstep_episode(env, seeds, policy):
+    obs = env.reset(seeds)
+    n = 0
+    t_env = 0.0
+    while True:
+        # one host sync per batched step (all envs finished?) -- part of the lockstep protocol
+        if not bool(obs.active.any()):
+            break
+        n += int(obs.active.sum())
+        a = policy(obs)
+        sync(); t0 = time.perf_counter()
+        obs = env.step(a)
+        sync(); t_env += time.perf_counter() - t0
+    return n, t_env
+
+
+def config1():
+    import oracle
+    inst, A = load_instances_npz(os.path.join(ROOT, "tests", "golden", "instances_20A50T.npz"))
+    one = {k: v[:1] for k, v in inst.items()}
+    seeds = env_seeds(0, 0, 1)
+    o = oracle.OracleEnv(A, 50).load(one["depot"][0], one["task_xy"][0], one["req"][0], one["dur"][0])
+    t0 = time.perf_counter(); reps = 200; n = 0
+    for r in range(reps):
+        o.clear_decisions()
+        n += o.rollout(int(seeds[0]), 0, oracle.POLICY_RANDOM, record=False)["n_steps"]
+    cpu = n / (time.perf_counter() - t0)
+    env = BatchedTaskEnv(1, A, 50, device=DEV).load_instances(**one)
+    lockstep_episode(env, seeds, lambda ob: random_valid_action(ob.mask))
+    sync(); t0 = time.perf_counter()
+    n2, t_env = lockstep_episode(env, seeds, lambda ob: random_valid_action(ob.mask))
+    wall = time.perf_counter() - t0
+    return dict(config=1, workload="1 env 20A/50T test-set instance 0", oracle_cpu_steps_per_s=cpu,
+                hip_lockstep_steps_per_s=n2 / wall, hip_env_only_us_per_step=t_env / n2 * 1e6,
+                reference_python_steps_per_s="~820 (BASELINE.md, survey container)")
+
+
+def config2_lockstep(B=4096, A=20, T=50):
+    inst = generate_batch(B, A, T, 0)
+    env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
+    seeds = env_seeds(0, 0, B)
+    lockstep_episode(env, seeds, lambda ob: random_valid_action(ob.mask))
+    sync(); t0 = time.perf_counter()
+    n, t_env = lockstep_episode(env, seeds, lambda ob: random_valid_action(ob.mask))
+    wall = time.perf_counter() - t0
+    W = algorithmic_bytes_per_step(A, T)
+    return dict(config="2-lockstep", workload=f"{B} envs {A}A/{T}T, dcm_step per decision + torch.multinomial policy",
+                steps_per_s_end_to_end=n / wall, steps_per_s_env_only=n / t_env,
+                env_only_hbm_frac=n / t_env * W / HBM_PEAK_BYTES_PER_S)
+
+
+def config3(B=4096, A=20, T=50):
+    from dcmrta_amd.policy import AttentionNet
+    torch.manual_seed(0)
+    net = AttentionNet().to(DEV).eval()
+    inst = generate_batch(B, A, T, 0)
+    env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
+    seeds = env_seeds(0, 0, B)
+
+    @torch.no_grad()
+    def policy(ob):
+        return torch.distributions.Categorical(logits=net(ob.tasks, ob.agents, ob.mask)).sample().to(torch.int32)
+    sync(); t0 = time.perf_counter()
+    n, t_env = lockstep_episode(env, seeds, policy)
+    wall = time.perf_counter() - t0
+    return dict(config=3, workload=f"{B} envs {A}A/{T}T, attention policy fp32 (2.1M params) + HIP env step",
+                steps_per_s_end_to_end=n / wall, steps_per_s_env_only=n / t_env, policy_share=1 - t_env / wall,
+                mean_reward=float(env.summary()[:, 0].mean()))
+
+
+def config4(B=8192, A=50, T=200, reps=3):
+    inst = generate_batch(B, A, T, 0)
+    env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
+    env.reset(env_seeds(0, 0, B), observe=False)
+    env.rollout_random(1)
+    sync(); t0 = time.perf_counter(); n = 0
+    for _ in range(reps):
+        n += int(env.rollout_random(1).sum())
+    sync(); dt = time.perf_counter() - t0
+    W = algorithmic_bytes_per_step(A, T)
+    return dict(config=4, workload=f"{B} envs/GPU {A}A/{T}T random-policy rollout (shard of 65536 over 8 GPUs)",
+                steps_per_s=n / dt, hbm_frac=n / dt * W / HBM_PEAK_BYTES_PER_S, decisions_per_episode=n / reps / B)
+
+
+def config5(B=1024, A=100, T=500):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_replay import synthetic_routes
+    inst = generate_batch(B, A, T, 0)
+    out = {}
+    for reactive in (False, True):
+        env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
+        env.load_routes([synthetic_routes(inst["req"][b], A, max_task=100 if reactive else None) for b in range(B)])
+        env.execute_routes(reactive)
+        sync(); t0 = time.perf_counter()
+        r = env.execute_routes(reactive)
+        sync(); dt = time.perf_counter() - t0
+        out["reactive" if reactive else "static"] = dict(agent_steps_per_s=int(r["steps"].sum()) / dt,
+                                                          mean_makespan=float(r["summary"][:, 3].mean()),
+                                                          success_rate=float(r["summary"][:, 2].mean()))
+    return dict(config=5, workload=f"{B} envs {A}A/{T}T route replay (execute_by_route), synthetic routes", **out,
+                reference_python="~400 agent-steps/s at 20A/50T (BASELINE.md)")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="all")
+    a = ap.parse_args()
+    table = {"1": config1, "2l": config2_lockstep, "3": config3, "4": config4, "5": config5}
+    for k in (table if a.config == "all" else [a.config]):
+        print(json.dumps(table[k]()), flush=True)
