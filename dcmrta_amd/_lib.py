@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcmrta_hip.so")
+# DCMRTA_HIP_LIB: developer override used by tools/variants.py to A/B differently-compiled builds of the same sources
+LIB_PATH = os.environ.get("DCMRTA_HIP_LIB") or os.path.join(_HERE, "libdcmrta_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 
 ABI_VERSION = 1

@@ -96,9 +96,11 @@ __device__ __forceinline__ double uni(double v) { return __longlong_as_double((l
 __device__ __forceinline__ Hdr load_hdr(const unsigned char* p) {
     const Hdr* q = (const Hdr*)p;
     Hdr h;
-    h.now = uni(q->now); h.seed = uni(q->seed); h.d = uni(q->d); h.depot_x = uni(q->depot_x); h.depot_y = uni(q->depot_y);
+    // hot fields only: depot / episodes / ep_steps stay in the LDS record (keeps the SGPR budget small)
+    h.now = uni(q->now); h.seed = uni(q->seed); h.d = uni(q->d);
     h.flags = uni(q->flags); h.cur_group = uni(q->cur_group); h.n_groups = uni(q->n_groups);
-    h.empty_passes = uni(q->empty_passes); h.ep_steps = uni(q->ep_steps); h.episodes = uni(q->episodes);
+    h.empty_passes = uni(q->empty_passes);
+    h.depot_x = 0.0; h.depot_y = 0.0; h.ep_steps = 0; h.episodes = 0;
     return h;
 }
 
@@ -215,7 +217,11 @@ __device__ __forceinline__ void copy16_in(unsigned char* dst, const unsigned cha
     for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = __builtin_nontemporal_load(s + i);
 }
 __device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
-    if (lane == 0) *(Hdr*)smem = h;
+    if (lane == 0) {
+        Hdr* q = (Hdr*)smem;
+        q->now = h.now; q->seed = h.seed; q->d = h.d; q->flags = h.flags; q->cur_group = h.cur_group;
+        q->n_groups = h.n_groups; q->empty_passes = h.empty_passes;
+    }
 }
 
 // ---------------------------------------------------------------------------------- host side

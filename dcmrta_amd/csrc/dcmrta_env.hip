@@ -33,6 +33,23 @@ int fail(int code, const char* fmt, const char* a, const char* b) {
 
 namespace {
 
+// Optional per-phase cycle accounting of the rollout kernel (tools/phase_profile.py builds a separate
+// libdcmrta_prof.so with -DDCM_PROFILE_PHASES; the product build compiles these macros to nothing).
+#ifdef DCM_PROFILE_PHASES
+__device__ unsigned long long g_phase_cycles[16];
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PH_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } while (0)
+#define PH_FLUSH(lane) do { if ((lane) == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); } while (0)
+#define PH_ARGS , unsigned long long& ph_t0, unsigned long long (&ph_acc)[12]
+#define PH_PASS , ph_t0, ph_acc
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH(lane)
+#define PH_ARGS
+#define PH_PASS
+#endif
+
 // ================================================================================== the simulator
 template <int CA, int CT>
 struct Sim {
@@ -114,14 +131,16 @@ struct Sim {
             const bool feas0 = info & T_FEAS;
             const int req = info & 0xFF;
             const int n = (info >> 16) & 0xFF;                               // :250
+            // Unused slots (j >= n) hold NaN in LDS (reset / compaction keep that invariant): v_max/v_min ignore
+            // them and every comparison against them is false, so no per-slot validity predicate is needed.
             double av[M];
 #pragma unroll
-            for (int j = 0; j < M; j++) av[j] = marr()[j * T_ + t];          // :251 (slots >= n are ignored below)
+            for (int j = 0; j < M; j++) av[j] = marr()[j * T_ + t];          // :251
             const double tfin = tf()[t], dur = tdur()[t];
             const int status = req - n;                                      // :252
-            double mx = -__builtin_inf(), mn = __builtin_inf();
+            double mx = av[0], mn = av[0];
 #pragma unroll
-            for (int j = 0; j < M; j++) { const bool v = j < n; mx = (v && av[j] > mx) ? av[j] : mx; mn = (v && av[j] < mn) ? av[j] : mn; }
+            for (int j = 1; j < M; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
             const bool le0 = status <= 0;                                    // :254
             const bool ok = le0 && (mx - mn <= mwt);                         // :255
             const double thr = mx - mwt;                                     // :262
@@ -129,12 +148,11 @@ struct Sim {
             bool prev = false;
 #pragma unroll
             for (int j = 0; j < M; j++) {
-                const bool v = j < n;
-                spread |= (uint32_t)(v && av[j] <= thr) << j;                // :262-265
+                spread |= (av[j] <= thr) ? (1u << j) : 0u;                   // :262-265
                 // :268-271 iterates task['members'] while removing from it: after a removal the element
                 // that slides into the freed slot is skipped by the list iterator (quirk Q1).
-                const bool e = v && !prev && (now - av[j] >= mwt);           // :269
-                q1 |= (uint32_t)e << j;
+                const bool e = !prev && (now - av[j] >= mwt);                // :269
+                q1 |= e ? (1u << j) : 0u;
                 prev = e;
             }
             const uint32_t drop = feas0 ? 0u : (le0 ? (ok ? 0u : spread) : q1);
@@ -158,6 +176,7 @@ struct Sim {
                             k++;
                         }
                     }
+                    for (int j = k; j < n; j++) marr()[j * T_ + t] = __builtin_nan("");   // vacated slots
                     mids()[t] = nids;
                     tnab()[t] += (uint32_t)(n - k);
                     nn = k;
@@ -220,25 +239,27 @@ struct Sim {
         }
         // :358-364 per agent in task order.  The +max_waiting_time terms of abandoned entries are added as
         // count*mwt after the member terms (the reference interleaves them in task order): equal to within
-        // a few ulp, see DESIGN.md "documented deviation".
+        // a few ulp, see DESIGN.md "documented deviation".  Membership: SWAR byte search in the packed id word.
         for (int a = lane; a < A_; a += WAVE) {
             double s = 0.;
+            const uint64_t pat = 0x0101010101010101ull * (uint64_t)(uint32_t)a;
             for (int t = 0; t < T_; t++) {
                 const uint32_t info = tinfo()[t];
                 const int n = (info >> 16) & 0xFF;
-                if (n == 0) continue;
-                const uint64_t ids = mids()[t];
-                int pos = -1;
-                for (int j = 0; j < n; j++) if ((int)((ids >> (8 * j)) & 0xFF) == a) pos = j;
-                if (pos < 0) continue;
-                const double mine = marr()[pos * T_ + t];
-                if (info & T_FEAS) {
-                    double mx = marr()[t];
-                    for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
-                    s += mx - mine;                                          // :360
-                } else {
-                    const double w = now - mine;
-                    s += (w > 0.) ? w : 0.;                                  // :362
+                const uint64_t x = mids()[t] ^ pat;
+                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
+                if (z) {
+                    const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                    const double mine = marr()[pos * T_ + t];
+                    if (info & T_FEAS) {
+                        double mx = marr()[t];
+                        for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
+                        s += mx - mine;                                      // :360
+                    } else {
+                        const double w = now - mine;
+                        s += (w > 0.) ? w : 0.;                              // :362
+                    }
                 }
             }
             s += (double)(ainfo()[a] >> 16) * mwt;                           // :363-364
@@ -275,7 +296,7 @@ struct Sim {
     __device__ __forceinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
         terminal_metrics(h.now, P.mwt, lane, row);
         h.flags |= DCM_FLAG_DONE;
-        h.episodes += 1;
+        if (lane == 0) ((Hdr*)base)->episodes += 1;   // cold header fields stay in the LDS record
         h.cur_group = 0;
     }
 
@@ -283,7 +304,7 @@ struct Sim {
     // Boxes D + A of SURVEY.md Appendix B: check_finished (worker.py:85, env/task_env.py:366-373), loop test
     // (worker.py:45), next_decision (:283-289), get_unique_group (:291-298), task_update, agent_update
     // (worker.py:50-51).  Returns at the next decision point or after terminal().
-    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS) const {
         const int A_ = A(), T_ = T();
         for (;;) {
             WSYNC();
@@ -372,9 +393,12 @@ struct Sim {
                 }
             }
             WSYNC();
+            PH_MARK(6);
             task_update(h, P, lane);                                          // worker.py:50
             WSYNC();
+            PH_MARK(7);
             agent_update(h, P, lane);                                         // worker.py:51
+            PH_MARK(8);
             if (!any) {
                 if (++h.empty_passes > 4) { h.flags |= DCM_FLAG_TRUNCATED; terminal(h, P, lane, row); return; }
                 continue;
@@ -394,17 +418,21 @@ struct Sim {
             tnab()[t] = 0;
             mids()[t] = 0;
             ts()[t] = 0.0; tf()[t] = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; j++) marr()[j * T() + t] = __builtin_nan("");   // empty member slots
         }
         for (int a = lane; a < A(); a += WAVE) {
-            ax()[a] = h.depot_x; ay()[a] = h.depot_y;      // :134
+            ax()[a] = ((const Hdr*)base)->depot_x; ay()[a] = ((const Hdr*)base)->depot_y;      // :134
             arr()[a] = 0.0; nd()[a] = 0.0; tdist()[a] = 0.0;  // :135
             cur()[a] = -2; ainfo()[a] = 0;
         }
-        h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0; h.ep_steps = 0;  // :139-140
+        h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0;  // :139-140
     }
 
     // ------------------------------------------------------------------------------ decisions
     // worker.py:54 -- the deciding agent of the current group (protocol slot 0), or the injected one
+    // (Keeping the group bitmask in SGPRs from one decision to the next was measured SLOWER: +12 % launch time from
+    // the extra SGPR pressure / spills, so it is recomputed with one LDS read + ballot per decision.)
     __device__ __forceinline__ int pick_leader(Hdr& h, int lane, int leader_in, uint64_t k1, AMask& gm) const {
         gm = group_mask(h.cur_group, lane);
         const int glen = am_count(gm);
@@ -421,7 +449,7 @@ struct Sim {
     __device__ __forceinline__ void observe(const Hdr& h, int lane, int leader, float* __restrict__ ag,
                                             float* __restrict__ tk, uint8_t* __restrict__ mask) const {
         const double now = h.now;
-        const double lx = uni(ax()[leader]), ly = uni(ay()[leader]);
+        const double lx = ax()[leader], ly = ay()[leader];
         const int A_ = A(), T_ = T();
         // get_current_agent_status, env/task_env.py:165-180
         if (ag) {
@@ -457,7 +485,7 @@ struct Sim {
         allmasked = __all(allmasked);
         if (lane == 0) {
             if (mask) mask[0] = allmasked ? 0 : 1;                            // worker.py:58-61
-            if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = (float)(h.depot_x - lx); tk[4] = (float)(h.depot_y - ly); }  // :188
+            if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = (float)(((const Hdr*)base)->depot_x - lx); tk[4] = (float)(((const Hdr*)base)->depot_y - ly); }  // :188
         }
     }
 
@@ -497,7 +525,7 @@ struct Sim {
     // task_update / agent_update (worker.py:74-76) and the move to the next decision point.
     __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
-                                                      const int16_t* __restrict__ fol_in, double* __restrict__ row) const {
+                                                      const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         AMask rest = gm0;
@@ -507,10 +535,7 @@ struct Sim {
 #pragma unroll
         for (int i = 0; i < NAW; i++) mm.w[i] = 0;
         am_set(mm, leader);
-        int ml[M];                                                            // ordered: leader, followers
-#pragma unroll
-        for (int j = 0; j < M; j++) ml[j] = -1;
-        ml[0] = leader;
+        uint64_t mlist = (uint64_t)(uint32_t)leader;                          // ordered member ids, byte j (task actions only)
         int nm = 1;
         double tx_, ty_;
         if (action == 0) {
@@ -519,7 +544,7 @@ struct Sim {
 #pragma unroll
             for (int i = 0; i < NAW; i++) mm.w[i] |= rest.w[i];
             nm += rlen; rlen = 0;
-            tx_ = h.depot_x; ty_ = h.depot_y;
+            tx_ = ((const Hdr*)base)->depot_x; ty_ = ((const Hdr*)base)->depot_y;
         } else {
             const int k = action - 1;
             const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
@@ -539,21 +564,23 @@ struct Sim {
                 }
                 am_clear(rest, f); rlen--;                                    // :332-333
                 am_set(mm, f);
-#pragma unroll
-                for (int q = 1; q < M; q++) if (q == nm) ml[q] = f;
+                mlist |= (uint64_t)(uint32_t)f << (8 * nm);
                 nm++;
             }
-            tx_ = uni(tx()[k]); ty_ = uni(ty()[k]);
+            tx_ = tx()[k]; ty_ = ty()[k];
         }
         // agent_step for every member (:300-324); independent per agent
+        double arrv[NAW];
 #pragma unroll
         for (int i = 0; i < NAW; i++) {
             const int a = i * 64 + lane;
+            arrv[i] = 0.0;
             if (a < A_ && ((mm.w[i] >> lane) & 1ull)) {
                 const double d = dist2(ax()[a], ay()[a], tx_, ty_);
                 const double travel_time = d / 0.2;                           // :315 velocity 0.2 (:99)
                 tdist()[a] += d;                                              // :317
-                arr()[a] = h.now + travel_time;                               // :318
+                arrv[i] = h.now + travel_time;                                // :318
+                arr()[a] = arrv[i];
                 ax()[a] = tx_; ay()[a] = ty_;                                 // :320
                 cur()[a] = action - 1;                                        // :314 route.append
                 uint32_t ai = ainfo()[a] & ~(A_GRP | A_MEMBER);               // leaves the pending group
@@ -561,39 +588,50 @@ struct Sim {
                 ainfo()[a] = ai;
             }
         }
-        WSYNC();
         if (action > 0) {
             // :321-322 members.append unless already listed; a re-joining agent keeps its slot but
-            // get_arrival_time (:202-205) now returns the new, later arrival (Q4)
+            // get_arrival_time (:202-205) now returns the new, later arrival (Q4).  Wave-uniform loop over the
+            // 1..5 members in order; "already listed" is a SWAR byte search in the packed ordered id word.
             const int k = action - 1;
             const uint32_t info = uni(tinfo()[k]);
             uint64_t ids = uni(mids()[k]);
             int n = (info >> 16) & 0xFF;
-            bool ovf = false;
-#pragma unroll
-            for (int j = 0; j < M; j++) if (j < nm) {
-                const int m = ml[j];
-                int pos = -1;
-#pragma unroll
-                for (int q = 0; q < M; q++) if (q < n && (int)((ids >> (8 * q)) & 0xFF) == m) pos = q;
-                if (pos < 0) {
-                    if (n >= M) { ovf = true; }
-                    else { pos = n++; ids = (ids & ~(0xFFull << (8 * pos))) | ((uint64_t)m << (8 * pos)); }
+            for (int j = 0; j < nm; j++) {
+                const int m = (int)((mlist >> (8 * j)) & 0xFF);
+                const uint64_t x = ids ^ (0x0101010101010101ull * (uint64_t)(uint32_t)m);
+                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // lowest set bit = first zero byte
+                z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
+                int pos;
+                if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                else {
+                    if (n >= M) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+                    pos = n++;
+                    ids |= (uint64_t)(uint32_t)m << (8 * pos);                // bytes above n are always zero
                 }
-                if (pos >= 0 && lane == 0) marr()[pos * T_ + k] = arr()[m];
+                double av = 0.0;                                              // arrival computed by agent m's lane above
+#pragma unroll
+                for (int i = 0; i < NAW; i++) if (i == (m >> 6)) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(arrv[i]), m & 63);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(arrv[i]), m & 63);
+                    av = __hiloint2double(hi, lo);
+                }
+                if (lane == 0) marr()[pos * T_ + k] = av;
             }
-            if (ovf) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
             if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
-        h.d += 1; h.ep_steps += 1;
+        h.d += 1;
         WSYNC();
+        PH_MARK(3);
         task_update(h, P, lane);                                              // worker.py:74
         WSYNC();
+        PH_MARK(4);
         agent_update(h, P, lane);                                             // worker.py:76
         WSYNC();
+        PH_MARK(5);
         if (rlen > 0) return;                                                 // worker.py:53 same group, next leader
         if (h.cur_group < h.n_groups) { h.cur_group++; return; }              // worker.py:52 next group
-        advance(h, P, lane, row);                                             // worker.py:85 -> :45
+        advance(h, P, lane, row PH_PASS);                                     // worker.py:85 -> :45
+        PH_MARK(9);
     }
 
     __device__ __forceinline__ void write_inactive_obs(int lane, float* ag, float* tk, uint8_t* mask) const {
@@ -634,10 +672,12 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    h.seed = seeds[e]; h.d = 0; h.episodes = 0;
+    h.seed = seeds[e]; h.d = 0;
+    if (lane == 0) ((Hdr*)smem)->episodes = 0;
     S.reset_state(h, lane);
     if (lane < 8) summary[(size_t)e * 8 + lane] = __builtin_nan("");
-    S.advance(h, P, lane, summary + (size_t)e * 8);
+    PH_DECL;
+    S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS);
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
@@ -693,8 +733,9 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
         const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm);
         if (leader >= 0) {
             const int nf = nfol_in ? nfol_in[e] : -1;
+            PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
-                                fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8);
+                                fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -738,23 +779,29 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
     double* row = summary + (size_t)e * 8;
     int64_t steps = 0;
+    PH_DECL;
     for (int ep = 0; ep < episodes; ep++) {
         if (h.flags & DCM_FLAG_DONE) {  // restart from the loaded instance; d keeps running
             if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) break;
             S.reset_state(h, lane);
-            S.advance(h, P, lane, row);
+            S.advance(h, P, lane, row PH_PASS);
+            PH_MARK(10);
         }
         while (!(h.flags & DCM_FLAG_DONE)) {
             AMask gm;
             const uint64_t k1 = key1(h.seed, h.d);
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
+            PH_MARK(0);
             S.observe(h, lane, leader, ag, tk, mk);
+            PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row);
+            PH_MARK(2);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS);
             steps++;
         }
     }
+    PH_FLUSH(lane);
     if (lane == 0 && steps_out) steps_out[e] = steps;
     WSYNC();
     store_hdr(h, lane);
@@ -1052,6 +1099,14 @@ int dcm_distance(const double* ax, const double* ay, const double* bx, const dou
     LAUNCH_OK();
     return DCM_OK;
 }
+
+#ifdef DCM_PROFILE_PHASES
+int dcm_prof_read(unsigned long long* out16, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    return DCM_OK;
+}
+#endif
 
 int dcm_record_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_ENV(env);

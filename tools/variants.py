@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""A/B different compile-time variants of the kernels on the GPU box (developer tool).
+
+    python tools/variants.py "name1:-DFLAG1 -DFLAG2" "name2:" ...
+
+Each variant is compiled to tools/_variants/lib_<name>.so and benchmarked with bench.py (interleaved, 2 rounds)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "dcmrta_amd", "csrc")
+out = os.path.join(ROOT, "tools", "_variants")
+os.makedirs(out, exist_ok=True)
+variants = []
+for spec in sys.argv[1:]:
+    name, _, flags = spec.partition(":")
+    so = os.path.join(out, f"lib_{name}.so")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+           "-shared"] + flags.split() + [os.path.join(src, "dcmrta_env.hip"), os.path.join(src, "dcmrta_replay.hip"), "-o", so]
+    subprocess.check_call(cmd)
+    variants.append((name, so))
+res = {n: [] for n, _ in variants}
+for rnd in range(2):
+    for name, so in variants:
+        env = dict(os.environ, DCMRTA_HIP_LIB=so)
+        o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                           env=env, capture_output=True, text=True)
+        line = [l for l in o.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            print(name, "FAILED", o.stderr[-400:])
+            continue
+        j = json.loads(line[-1])
+        res[name].append(j["roofline"]["avg_launch_ms"])
+for name, v in res.items():
+    print(f"{name:24s} launch ms: " + " ".join(f"{x:.4f}" for x in v))
