@@ -281,10 +281,10 @@ struct Sim {
         }
         // :422 check_finished() once more can only re-assign the same `now`
         const double Td = (double)T_, Ad = (double)A_;
-        const double m2 = psum<3>(ts(), T_) / Td;      // np.nanmean(time_start)      worker.py:105
-        const double m3 = psum<3>(aw(), A_) / Ad;      // np.mean(agent sum_waiting)  :106
-        const double m4 = psum<3>(tdist(), A_);        // np.sum(travel_dist)         :107
-        const double m5 = psum<3>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
+        const double m2 = psum<4>(ts(), T_) / Td;      // np.nanmean(time_start)      worker.py:105
+        const double m3 = psum<4>(aw(), A_) / Ad;      // np.mean(agent sum_waiting)  :106
+        const double m4 = psum<4>(tdist(), A_);        // np.sum(travel_dist)         :107
+        const double m5 = psum<4>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
         if (lane == 0 && row) {
             row[0] = -now;                             // reward, env/task_env.py:424
             row[1] = (double)nfin;

@@ -390,8 +390,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         nfin += __popcll(__ballot(t < T && (R.tinfo()[t < T ? t : 0] & T_FIN)));
     }
     const double Td = (double)T, Ad = (double)A;
-    const double m2 = psum<3>(R.ts(), T) / Td, m3 = psum<3>(R.aw(), A) / Ad, m4 = psum<3>(R.tdist(), A),
-                 m5 = psum<3>(R.tw(), T) / Td;
+    const double m2 = psum<4>(R.ts(), T) / Td, m3 = psum<4>(R.aw(), A) / Ad, m4 = psum<4>(R.tdist(), A),
+                 m5 = psum<4>(R.tw(), T) / Td;
     if (lane == 0) {
         double* row = summary + (size_t)e * 8;
         row[0] = -now; row[1] = (double)nfin; row[2] = (double)nfin / Td; row[3] = now;

@@ -1,0 +1,126 @@
+"""-m gpu: behaviour of the C-ABI surface itself -- purity of observe, snapshot/restore (copy.deepcopy of worker.py:33),
+per-env error flags, inactive envs, maximum sizes, size-independent properties at BASELINE's full sizes."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(B, A, T, dev, seed=0):
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import generate_batch
+    inst = generate_batch(B, A, T, base_seed=seed)
+    return BatchedTaskEnv(B, A, T, device=dev).load_instances(**inst), inst
+
+
+def test_observe_is_pure_and_matches_fused_observe(gpu_device):
+    from dcmrta_amd.choice import env_seeds
+    env, _ = _mk(32, 20, 50, gpu_device)
+    obs = env.reset(env_seeds(1, 0, 32))
+    for _ in range(15):
+        a = [t.clone() for t in (obs.agents, obs.tasks, obs.mask, obs.leader, obs.active)]
+        again = env.observe()
+        for x, y in zip(a, (again.agents, again.tasks, again.mask, again.leader, again.active)):
+            assert torch.equal(x, y)
+        act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()
+        obs = env.step(act)
+
+
+def test_clone_restore_replays_identically(gpu_device):
+    """Greedy-twin use of worker.py:33,89: snapshot, run, restore, run again -> same episode."""
+    from dcmrta_amd.choice import env_seeds
+    env, _ = _mk(64, 20, 50, gpu_device, seed=5)
+    env.reset(env_seeds(2, 0, 64), observe=False)
+    for _ in range(7):
+        obs = env.observe()
+        env.step(torch.multinomial((~obs.mask).float(), 1).squeeze(1).int(), observe=False)
+    snap = env.clone_state()
+    s1 = env.rollout_random(1).clone()
+    r1 = env.summary().clone()
+    env.restore_state(snap)
+    s2 = env.rollout_random(1)
+    assert torch.equal(s1, s2) and torch.equal(r1, env.summary())
+
+
+def test_error_flags_freeze_only_the_offending_env(gpu_device):
+    from dcmrta_amd import _lib
+    from dcmrta_amd.choice import env_seeds
+    env, _ = _mk(4, 6, 9, gpu_device)
+    obs = env.reset(env_seeds(3, 0, 4))
+    act = torch.ones(4, dtype=torch.int32, device=gpu_device)
+    act[1] = 99       # out of range -> BAD_ACTION
+    act[2] = -3
+    obs = env.step(act)
+    flags = env.status()["flags"].cpu().numpy()
+    assert flags[1] & _lib.FLAG_BAD_ACTION and flags[2] & _lib.FLAG_BAD_ACTION and flags[1] & _lib.FLAG_DONE
+    assert flags[0] == 0 and flags[3] == 0
+    assert obs.active.cpu().tolist() == [True, False, False, True]
+    assert obs.leader[1] == -1 and obs.mask[1].cpu().tolist() == [False] + [True] * 9   # inactive rows: only the depot unmasked
+    # injected leader that is not deciding
+    obs2 = env.observe(leader=np.array([0, -1, -1, 0], np.int32))
+    env.step(torch.ones(4, dtype=torch.int32, device=gpu_device), leader=np.array([-1, -1, -1, 5], np.int32), observe=False)
+    # agent 5 decided at t=0 unless it already left with a previous leader; either it moved or BAD_LEADER is raised
+    st = env.status()["flags"].cpu().numpy()
+    assert st[3] in (0, _lib.FLAG_BAD_LEADER | _lib.FLAG_DONE)
+    nan_rows = torch.isnan(env.summary()[:, 0]).cpu().numpy()
+    assert nan_rows.all()   # nobody finished an episode yet -> summary rows are NaN
+
+
+def test_api_state_errors(gpu_device):
+    from dcmrta_amd import _lib
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    env = BatchedTaskEnv(2, 3, 4, device=gpu_device)
+    with pytest.raises(_lib.DcmError):
+        env.reset(np.zeros(2, np.uint64))            # no instances loaded
+    with pytest.raises(_lib.DcmError):
+        env.load_instances(np.zeros((2, 2)), np.zeros((2, 4, 2)), np.full((2, 4), 6), np.ones((2, 4)))  # requirement > 5
+    with pytest.raises(_lib.DcmError):
+        BatchedTaskEnv(2, 300, 4, device=gpu_device)  # A > DCM_MAX_AGENTS
+
+
+@pytest.mark.parametrize("A,T", [(128, 1023), (128, 64), (1, 1023), (64, 1)])
+def test_limit_sizes_match_oracle(gpu_device, oracle_lib, A, T):
+    from dcmrta_amd.choice import env_seeds
+    env, inst = _mk(2, A, T, gpu_device, seed=70)
+    seeds = env_seeds(5, 0, 2)
+    env.reset(seeds, observe=False)
+    steps = env.rollout_random(1).cpu().numpy()
+    fin = H.gpu_final(env)
+    for b in range(2):
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, cap_steps=50000, record=False)
+        assert steps[b] == ref["n_steps"]
+        H.assert_final_matches(fin[b], ref, f"{A}A{T}T env{b}")
+
+
+def test_full_size_properties(gpu_device):
+    """BASELINE full sizes (4096 x 20A/50T, 8192 x 50A/200T): properties that do not need the oracle."""
+    from dcmrta_amd.choice import env_seeds
+    for B, A, T in ((4096, 20, 50), (8192, 50, 200)):
+        env, inst = _mk(B, A, T, gpu_device)
+        seeds = env_seeds(0, 0, B)
+        env.reset(seeds, observe=False)
+        s1 = env.rollout_random(1).clone()
+        sm1 = env.summary().clone()
+        ts = {k: v.clone() for k, v in env.tasks_state().items()}
+        ag = {k: v.clone() for k, v in env.agents_state().items()}
+        # determinism: same seeds -> identical episode
+        env.reset(seeds, observe=False)
+        assert torch.equal(env.rollout_random(1), s1) and torch.equal(env.summary(), sm1)
+        sm = sm1.cpu().numpy()
+        assert np.isfinite(sm).all() and (env.status()["flags"].cpu().numpy() & 0x7C).sum() == 0
+        fin, feas = ts["finished"].cpu().numpy().astype(bool), ts["feasible"].cpu().numpy().astype(bool)
+        assert not (fin & ~feas).any()                                   # finished => feasible
+        assert np.array_equal(fin.sum(1), sm[:, 1].astype(int))          # n_finished is the checksum of the flags
+        assert np.allclose(sm[:, 2], fin.mean(1)) and np.array_equal(sm[:, 0], -sm[:, 3])
+        nm, req = ts["n_members"].cpu().numpy(), inst["req"]
+        assert (nm <= req).all() and (nm[feas] == req[feas]).all()       # coalition size: <= requirement, == when formed
+        tstart, tfin, dur = ts["time_start"].cpu().numpy(), ts["time_finish"].cpu().numpy(), inst["dur"]
+        assert np.array_equal(tfin[feas], (tstart + dur)[feas])
+        assert np.array_equal(ag["travel_dist"].sum(1).cpu().numpy() > 0, np.ones(B, bool))
+        # a makespan beyond MAX_TIME only through quirk Q7 (the event that crosses 100 is processed completely)
+        assert (sm[:, 3] < 100 + 10 + 5 * 2 ** 0.5 + 5).all()
+        assert int(s1.min()) > 0
