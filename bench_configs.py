@@ -6,6 +6,7 @@
 Prints one JSON line per config (1 GPU; config 4's sharded variant is bench.py --gpus N --envs 8192 --agents 50 --tasks 200):
   1   1 env, 20A/50T test-set instance 0: oracle (CPU, 1 thread) vs HIP lockstep, per-step latency
   2l  config 2 through the LOCKSTEP API (dcm_step per decision, uniform-random valid action chosen by a torch op)
+  2g  the same loop as eager launches vs ONE HIP graph per decision
   3   4096 envs 20A/50T, attention policy (stock PyTorch-ROCm) + HIP env step: env-only and end-to-end
   4   8192 envs/GPU 50A/200T random-policy rollout (the per-GPU shard of 65536 envs over 8 GPUs)
   5   100A/500T route replay, synthetic routes, with/without dynamic visibility
@@ -90,6 +91,31 @@ def config2_lockstep(B=4096, A=20, T=50):
                 env_only_hbm_frac=n / t_env * W / HBM_PEAK_BYTES_PER_S)
 
 
+def config2_graph(A=20, T=50):
+    """Same lockstep loop, eager launches vs one HIP graph per decision (dcmrta_amd/graph_rollout.py)."""
+    from dcmrta_amd.graph_rollout import GraphedRollout
+    out = {}
+    for B in (256, 4096):
+        inst = generate_batch(B, A, T, 0)
+        env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
+        seeds = env_seeds(0, 0, B)
+        pol = lambda ob: torch.multinomial((~ob.mask).float(), 1).squeeze(1)
+        obs = env.reset(seeds)
+        sync(); t0 = time.perf_counter(); k = 0
+        while k < 400:
+            for _ in range(8):
+                obs = env.step(pol(obs).int()); k += 1
+            if not bool(obs.active.any()):
+                break
+        sync(); eager = (time.perf_counter() - t0) / k
+        g = GraphedRollout(env, pol, check_every=8).capture(seeds)
+        sync(); t0 = time.perf_counter()
+        _, n = g.run(seeds)
+        sync(); graphed = (time.perf_counter() - t0) / n
+        out[f"B{B}"] = dict(eager_us_per_batched_step=eager * 1e6, graph_us_per_batched_step=graphed * 1e6)
+    return dict(config="2-graph", workload=f"{A}A/{T}T lockstep loop (torch.multinomial policy + dcm_step), eager vs HIP graph", **out)
+
+
 def config3(B=4096, A=20, T=50):
     from dcmrta_amd.policy import AttentionNet
     torch.manual_seed(0)
@@ -146,6 +172,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
     a = ap.parse_args()
-    table = {"1": config1, "2l": config2_lockstep, "3": config3, "4": config4, "5": config5}
+    table = {"1": config1, "2l": config2_lockstep, "2g": config2_graph, "3": config3, "4": config4, "5": config5}
     for k in (table if a.config == "all" else [a.config]):
         print(json.dumps(table[k]()), flush=True)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""k_step (lockstep API) throughput probe: B envs, N batched steps, device-side random policy, no host sync in the loop."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dcmrta_amd.batched_env import BatchedTaskEnv
+from dcmrta_amd.choice import env_seeds
+from dcmrta_amd.instances import generate_batch
+from dcmrta_amd.roofline import algorithmic_bytes_per_step
+
+B, A, T, N = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (65536, 20, 50, 60)))
+env = BatchedTaskEnv(B, A, T).load_instances(**generate_batch(B, A, T, 0))
+obs = env.reset(env_seeds(0, 0, B))
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(N)]
+for i in range(N):
+    act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()
+    ev[i][0].record()
+    obs = env.step(act)
+    ev[i][1].record()
+torch.cuda.synchronize()
+ms = sorted(a.elapsed_time(b) for a, b in ev)
+med = ms[len(ms) // 2]
+W = algorithmic_bytes_per_step(A, T)
+print(f"B={B} {A}A/{T}T k_step median {med*1e3:.1f} us  -> {B/med*1e3:.3e} steps/s, {B*W/med/1e6:.0f} GB/s algorithmic "
+      f"({B*W/med/1e6/8000*100:.1f} % of 8 TB/s)")

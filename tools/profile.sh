@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe used for profiles/ (run on the GPU box through gpurun).
-#   bash tools_profile.sh <tag>   ->  gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}
+#   bash tools/profile.sh <tag>   ->  gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}
 set -u
 TAG=${1:-r01}
 REPO=$(pwd)
