@@ -51,6 +51,7 @@ SIGNATURES = {
     "dcm_restore_state": (C.c_int, [_vp] * 3),
     "dcm_distance": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dcm_record_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "dcm_set_route_log": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),
     "dcm_load_routes": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dcm_execute_routes": (C.c_int, [_vp, _i32] + [_vp] * 11),
 }

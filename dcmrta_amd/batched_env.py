@@ -196,6 +196,20 @@ class BatchedTaskEnv:
             check(self._lib.dcm_get_agents(self._h, *[_ptr(v) for v in o.values()], self._stream()))
         return o
 
+    # ------------------------------------------------------------------ route history (agent['route'], agent['arrival_time'])
+    def enable_route_log(self, cap=64):
+        """Record every agent_step of the lockstep API (reset / step): route_task[B,A,cap] (-1 = depot), route_arrival, route_len."""
+        B, A, dev = self.B, self.A, self.device
+        self._route = (torch.full((B, A, cap), -2, dtype=torch.int16, device=dev),
+                       torch.zeros((B, A, cap), dtype=torch.float64, device=dev),
+                       torch.zeros((B, A), dtype=torch.int32, device=dev))
+        check(self._lib.dcm_set_route_log(self._h, *[_ptr(x) for x in self._route], int(cap)))
+        return self
+
+    def routes(self):
+        """(task[B,A,cap], arrival[B,A,cap], length[B,A]) recorded since the last reset."""
+        return self._route
+
     # ------------------------------------------------------------------ route replay (env/task_env.py:562-599)
     def load_routes(self, routes, member_cap=8):
         """routes[b][a] = list of actions (0 = depot, k = task k-1) or None (pre_set_route stays None)."""

@@ -72,6 +72,14 @@ struct KP {
     double max_time;  // MAX_TIME
 };
 
+// optional route history of the lockstep API (agent['route'] / agent['arrival_time'], env/task_env.py:95-96,314,318)
+struct RouteLog {
+    int16_t* task;    // [B][A][cap]  task id, -1 = depot
+    double* arrival;  // [B][A][cap]
+    int32_t* len;     // [B][A]
+    int32_t cap;
+};
+
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 // One wavefront == one workgroup: LDS instructions of a wave execute in program order, so cross-lane
@@ -249,4 +257,5 @@ struct dcm_env {
     int32_t* routes = nullptr;       // [B][A][route_cap] actions
     int32_t* route_len = nullptr;    // [B][A], -1 = pre_set_route is None
     int32_t route_cap = 0, member_cap = 0;
+    dcm::RouteLog log{nullptr, nullptr, nullptr, 0};   // dcm_set_route_log
 };

@@ -525,7 +525,8 @@ struct Sim {
     // task_update / agent_update (worker.py:74-76) and the move to the next decision point.
     __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
-                                                      const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS) const {
+                                                      const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
+                                                      const RouteLog* log = nullptr, int env_index = 0) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         AMask rest = gm0;
@@ -586,6 +587,12 @@ struct Sim {
                 uint32_t ai = ainfo()[a] & ~(A_GRP | A_MEMBER);               // leaves the pending group
                 ai |= (action == 0) ? A_INDEPOT : A_MEMBER;                   // :321-322 listed in the target's members
                 ainfo()[a] = ai;
+                if (log && log->len) {                                        // route.append / arrival_time += (:314,:318)
+                    const size_t o = (size_t)env_index * A_ + a;
+                    const int c = log->len[o];
+                    if (c < log->cap) { log->task[o * log->cap + c] = (int16_t)(action - 1); log->arrival[o * log->cap + c] = arrv[i]; }
+                    log->len[o] = c + 1;
+                }
             }
         }
         if (action > 0) {
@@ -717,7 +724,7 @@ template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char* state, const int32_t* actions,
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
-                                              int32_t* leader_out, uint8_t* active_out, double* summary) {
+                                              int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     using AMask = typename Sim<CA, CT>::AMask;
@@ -735,7 +742,8 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
             const int nf = nfol_in ? nfol_in[e] : -1;
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
-                                fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS);
+                                fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
+                                &log, e);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -975,7 +983,18 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();
+    if (env->log.len)
+        HIP_TRY(hipMemsetAsync(env->log.len, 0, (size_t)env->p.n_envs * env->L.A * sizeof(int32_t), (hipStream_t)stream));
     env->reset_done = true;
+    return DCM_OK;
+}
+
+int dcm_set_route_log(dcm_env* env, int16_t* route_task, double* route_arrival, int32_t* route_len, int32_t cap) {
+    CHECK_ENV(env);
+    const bool off = !route_task && !route_arrival && !route_len;
+    if (!off && (!route_task || !route_arrival || !route_len || cap < 1))
+        return fail(DCM_ERR_INVALID, "dcm_set_route_log: give all three arrays and cap >= 1, or all NULL");
+    env->log = RouteLog{route_task, route_arrival, route_len, off ? 0 : cap};
     return DCM_OK;
 }
 
@@ -1003,7 +1022,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
 #define CALL(CA, CT)                                                                                                 \
     hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary)
+                       active_out, env->summary, env->log)
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();

@@ -110,6 +110,14 @@ int dcm_step(dcm_env *env, const int32_t *actions, const int32_t *leader_in, con
              const int16_t *followers_in, float *agents_out, float *tasks_out, uint8_t *mask_out,
              int32_t *leader_out, uint8_t *active_out, void *stream);
 
+/* Optional route history = agent['route'] / agent['arrival_time'] of the reference (env/task_env.py:95-96,314,318), the
+ * input of generate_traj / generate_route (env/task_env.py:375-418, worker.py:244-251).  When set, every agent_step
+ * executed by dcm_step appends (task id, -1 = depot; arrival time) to the agent's log:
+ * route_task[B,A,cap] i16, route_arrival[B,A,cap] f64, route_len[B,A] i32 -- caller-owned device memory that must
+ * outlive its use; all NULL disables.  dcm_reset zeroes route_len; entries beyond cap are counted but not stored.
+ * (dcm_rollout_random does not log: use the lockstep API when trajectories are wanted.) */
+int dcm_set_route_log(dcm_env *env, int16_t *route_task, double *route_arrival, int32_t *route_len, int32_t cap);
+
 /* Config-2 hot path: every env plays `episodes` complete episodes under the uniform-random valid
  * policy inside ONE persistent launch (worker.py:45-87 with the action drawn from slot 1 of the
  * protocol); the observation tensors + mask are produced at every decision exactly as dcm_observe

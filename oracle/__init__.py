@@ -71,6 +71,8 @@ def lib():
         L.orc_summary_get.argtypes = [vp, C.POINTER(_Summary)]
         L.orc_final_tasks.argtypes = [vp] * 8
         L.orc_final_agents.argtypes = [vp] * 5
+        L.orc_get_route.restype = C.c_int
+        L.orc_get_route.argtypes = [vp, C.c_int, vp, vp, C.c_int]
         L.orc_pre_set_route.argtypes = [vp, C.c_int, vp, C.c_int]
         L.orc_execute_by_route.restype = C.c_int
         L.orc_execute_by_route.argtypes = [vp, C.c_int]
@@ -215,6 +217,12 @@ class OracleEnv:
         return dict(reward=s.reward, makespan=s.makespan, metrics=np.array(list(s.metrics)), truncated=int(s.truncated),
                     finished=fin, feasible=fea, time_start=ts, time_finish=tf, task_wait=tw, n_members=nm,
                     n_abandoned=na, agent_wait=aw, travel_dist=td, returned=ret, route_len=rl)
+
+    def route(self, agent, cap=4096):
+        """(route, arrival_time) lists of the agent (env/task_env.py:95-96)."""
+        t, a = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        n = lib().orc_get_route(self._h, int(agent), _p(t), _p(a), cap)
+        return t[:n].copy(), a[:n].copy()
 
     # route replay --------------------------------------------------------------------------
     def pre_set_route(self, actions, agent):

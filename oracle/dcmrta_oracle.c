@@ -479,6 +479,12 @@ void orc_final_agents(orc_env *e, double *agent_wait, double *travel_dist, uint8
     }
 }
 
+int orc_get_route(orc_env *e, int agent, int32_t *tasks_out, double *arrival_out, int cap) {
+    int n = e->route[agent].n;
+    for (int i = 0; i < n && i < cap; i++) { tasks_out[i] = e->route[agent].v[i]; arrival_out[i] = e->arrival[agent].v[i]; }
+    return n;
+}
+
 /* ------------------------------------------------------------------ RL-mode episode (worker.py:45-87) */
 static int policy_pick(orc_env *e, int policy, const uint8_t *mask, int leader, uint64_t seed_e, uint64_t d) {
     int T1 = e->T + 1;

@@ -80,6 +80,9 @@ void orc_final_tasks(orc_env *e, uint8_t *finished, uint8_t *feasible, double *t
                      double *task_wait, int32_t *n_members, int32_t *n_abandoned);
 void orc_final_agents(orc_env *e, double *agent_wait, double *travel_dist, uint8_t *returned, int32_t *route_len);
 
+/* agent['route'] / agent['arrival_time'] (env/task_env.py:95-96): copies up to cap entries, returns the route length */
+int orc_get_route(orc_env *e, int agent, int32_t *tasks_out, double *arrival_out, int cap);
+
 /* route replay: env/task_env.py:595-599 (pre_set_route), :562-593 (execute_by_route) */
 void orc_pre_set_route(orc_env *e, int agent, const int32_t *actions, int n);
 /* returns 0 ok, -2 if the reference would raise TypeError at :220 (pre_set_route None) */

@@ -67,3 +67,44 @@ def test_record_size_formula():
     from dcmrta_amd.roofline import algorithmic_bytes_per_step, state_bytes
     assert state_bytes(20, 50) == 5824 and algorithmic_bytes_per_step(20, 50) == 13203
     assert algorithmic_bytes_per_step(50, 200) == 48753 and algorithmic_bytes_per_step(100, 500) == 118653
+
+
+def test_ctasd_yaml_export_matches_shipped_files(golden_dir, tmp_path):
+    """dcmrta_amd.ctasd_io against the planner inputs the reference ships (written by TestSetGenerator.py:40-116)."""
+    import hashlib
+    import json
+
+    import yaml
+    from dcmrta_amd.ctasd_io import export_ctasd_yaml
+    from dcmrta_amd.instances import load_instances_npz
+    inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    dig = json.load(open(os.path.join(golden_dir, "ctasd_yaml_digest.json")))
+    for i, ref in dig.items():
+        i = int(i)
+        folder = ref["planner_param"]["graphFile"].split("/")[1]
+        export_ctasd_yaml(str(tmp_path / f"env_{i}"), inst["depot"][i], inst["task_xy"][i], inst["req"][i], inst["dur"][i], A,
+                          folder=folder, index=i, solver_time=ref["planner_param"]["solverMaxTime"])
+        for name, want in ref["sha256"].items():
+            doc = yaml.safe_load(open(tmp_path / f"env_{i}" / f"{name}.yaml"))
+            got = hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest()
+            assert got == want, (i, name)
+        # graph.yaml: same keys in the same order, same integer columns; weights to 1e-14 (the shipped files were written
+        # with an older math.hypot that differs in the last ulp)
+        g = yaml.safe_load(open(tmp_path / f"env_{i}" / "graph.yaml"))["vehicle0"]
+        assert hashlib.sha256(json.dumps(list(g.keys()), sort_keys=True).encode()).hexdigest() == ref["graph_keys_sha256"]
+        z = np.load(os.path.join(golden_dir, "ctasd_graph.npz"))
+        edges = [k for k in g if k.startswith("edge")]
+        assert np.array_equal(np.array([[g[k][0], g[k][1], g[k][2], g[k][4]] for k in edges]), z[f"ends_{i}"])
+        np.testing.assert_allclose([g[k][3] for k in edges], z[f"dist_{i}"], rtol=1e-14)
+        np.testing.assert_allclose([g[k][5] for k in edges], z[f"time_{i}"], rtol=1e-14)
+        assert np.array_equal(np.array([g[k] for k in g if k.startswith("node")]), z[f"node_{i}"])
+
+
+def test_read_ctasd_routes(tmp_path):
+    import yaml
+    from dcmrta_amd.ctasd_io import read_ctasd_routes
+    (tmp_path / "p.yaml").write_text(yaml.dump({"flagSolver": "TEAMPLANNER_CONDET", "vehNum": 1, "vehNumPerType": [3]}))
+    (tmp_path / "r.yaml").write_text(yaml.dump({"vehicle": {"vv1": {"node": [0, 3, 1, 0]}, "vv2": {"node": [0]}, "vv3": {"node": [0, 2, 0]}}}))
+    assert read_ctasd_routes(tmp_path / "r.yaml", tmp_path / "p.yaml") == [[3, 1, 0], None, [2, 0]]
+    (tmp_path / "r2.yaml").write_text(yaml.dump({"result": {"flagSuccess": 0}}))
+    assert read_ctasd_routes(tmp_path / "r2.yaml", tmp_path / "p.yaml") is None
