@@ -35,3 +35,22 @@ for rnd in range(2):
         res[name].append(j["roofline"]["avg_launch_ms"])
 for name, v in res.items():
     print(f"{name:24s} launch ms: " + " ".join(f"{x:.4f}" for x in v))
+if os.environ.get("VARIANTS_PMC"):   # per-decision instruction counts of k_rollout_random for every variant
+    import collections
+    import csv
+    import glob
+    import shutil
+    for name, so in variants:
+        d = os.path.join(out, f"pmc_{name}")
+        shutil.rmtree(d, ignore_errors=True)
+        env = dict(os.environ, DCMRTA_HIP_LIB=so, TMPDIR="/tmp")
+        subprocess.run(["rocprofv3", "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
+                        "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "x", "--",
+                        "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, cwd="/tmp")
+        agg = collections.defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_rollout_random" in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(name, {k: round(sum(v) / len(v) / 490700.0, 1) for k, v in sorted(agg.items())})
