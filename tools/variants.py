@@ -51,6 +51,6 @@ if os.environ.get("VARIANTS_PMC"):   # per-decision instruction counts of k_roll
         agg = collections.defaultdict(list)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "k_rollout_random" in r["Kernel_Name"]:
+                if "k_rollout" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(name, {k: round(sum(v) / len(v) / 490700.0, 1) for k, v in sorted(agg.items())})
