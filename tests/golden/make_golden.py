@@ -143,6 +143,10 @@ def rollout(env, seed_e, policy, d0=0, record=True, quirks=None):
         ids, t = env.next_decision()  # :47
         groups = env.get_unique_group(ids) if len(ids) else []  # :48
         env.current_time = t  # :49
+        if quirks is not None:
+            _count_q1(env, quirks)
+            if len(groups) > 1:
+                quirks["multi_group_events"] = quirks.get("multi_group_events", 0) + 1
         env.task_update()  # :50
         env.agent_update()  # :51
         if len(groups) == 0:
@@ -210,6 +214,18 @@ def _follower_order(seed_e, d, before, leader, k):
     for j in range(k):
         out.append(rest.pop(below(draw(seed_e, d, 2 + j), len(rest))))
     return out
+
+
+def _count_q1(env, q):
+    """Q1 (env/task_env.py:268-271): two consecutive members expire in the same update -> the second one is skipped."""
+    for t in env.task_dic.values():
+        if t["feasible_assignment"] or len(t["members"]) < 2:
+            continue
+        if int(np.asarray(t["requirements"]).reshape(-1)[0]) - len(t["members"]) <= 0:
+            continue
+        ex = [env.current_time - env.get_arrival_time(m, t["ID"]) >= env.max_waiting_time for m in t["members"]]
+        if any(a and b for a, b in zip(ex, ex[1:])):
+            q["Q1_skip_after_removal"] = q.get("Q1_skip_after_removal", 0) + 1
 
 
 def _count_quirks_pre(env, action, leader, q):
@@ -395,6 +411,32 @@ def main():
         print(name, int(tr["n_steps"]), float(tr["reward"]), int(tr["finished"].sum()), flush=True)
     with open(f"{OUT}/trace_hashes.json", "w") as f:
         json.dump(hashes, f, indent=1)
+
+    # G6 micro-scenario: exact time ties at DIFFERENT locations -> several groups per event, ordered like the rows of
+    # np.unique(axis=0) (env/task_env.py:291-298).  Symmetric instance: four requirement-1 tasks at distance 0.25 from
+    # the depot, so the four agents sent there alone arrive and finish at identical times.
+    for name, A, xy, req in (
+            ("ties4", 4, [(0.75, 0.5), (0.5, 0.75), (0.25, 0.5), (0.5, 0.25), (0.1, 0.9), (0.9, 0.1), (0.3, 0.3), (0.7, 0.7)], [1] * 8),
+            ("ties2y", 2, [(0.5, 0.75), (0.5, 0.25), (0.2, 0.2), (0.8, 0.8), (0.8, 0.2)], [1, 1, 2, 1, 1]),
+            ("ties_mixed", 6, [(0.25, 0.5), (0.75, 0.5), (0.5, 0.25), (0.5, 0.75), (0.25, 0.25), (0.75, 0.75), (0.1, 0.5)],
+             [2, 2, 1, 1, 3, 1, 2])):
+        T = len(req)
+        env = TaskEnv((A, A), (T, T), 1, 5, seed=0)
+        dep = np.array([0.5, 0.5])
+        for i in range(T):
+            env.task_dic[i]["location"] = np.array(xy[i], dtype=np.float64)
+            env.task_dic[i]["requirements"] = np.array([req[i]])
+            env.task_dic[i]["status"] = np.array([req[i]])
+        env.depot["location"] = dep
+        for a in env.agent_dic.values():
+            a["location"] = dep
+            a["depot"] = dep
+        env.clear_decisions()
+        ia = instance_arrays(env)
+        se = env_seed(4000, T)
+        tr = rollout(env, se, POLICIES["first"], quirks=quirks)
+        np.savez_compressed(f"{OUT}/micro_{name}.npz", seed_e=np.uint64(se), inst_seed=np.int64(-1), **ia, **tr)
+        print("micro", name, int(tr["n_steps"]), float(tr["reward"]), flush=True)
 
     # test-set instances in RL mode (pkl durations are U(0,5), requirement 1..5): 6 hashed traces
     ts_hash = {}

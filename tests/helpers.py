@@ -14,7 +14,13 @@ FINAL_EXACT = ("finished", "feasible", "time_start", "time_finish", "task_wait",
 
 
 def full_traces():
-    return sorted(glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+    """Full golden step traces: trace_<A>A<T>T_<policy>_s<seed>.npz and the hand-built tie scenarios micro_*.npz."""
+    return sorted(glob.glob(os.path.join(GOLDEN, "trace_*.npz"))) + sorted(glob.glob(os.path.join(GOLDEN, "micro_*.npz")))
+
+
+def trace_policy(path):
+    base = os.path.basename(path)
+    return "first" if base.startswith("micro_") else base.split("_")[2]
 
 
 def load_trace(path):
@@ -82,7 +88,8 @@ def run_lockstep(env, seeds, policy, inject=None, max_iters=100000):
             r["mask"].append(mk[b].copy()); r["agents_obs"].append(ag[b].copy()); r["tasks_obs"].append(tk[b].copy())
             if inject is not None:
                 nfol[b] = inject["nfol"][b][i]
-                fol[b] = inject["followers"][b][i][:4]
+                f = inject["followers"][b][i][:4]
+                fol[b, :len(f)] = f
                 if a == 0:
                     nfol[b] = -1  # depot: the whole group leaves, nothing to inject
                 if i + 1 < len(inject["leader"][b]):

@@ -57,3 +57,31 @@ def test_fast_and_default_kernels_agree_on_observations(gpu_device, fast_kernel)
         outs.append([x.clone() for x in (steps, obs.agents, obs.tasks, obs.mask, env.summary())])
     for a, b in zip(*outs):
         assert (a == b).all() or (a.is_floating_point() and ((a == b) | (a.isnan() & b.isnan())).all())
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_rollout_kernels_on_tie_instances(gpu_device, oracle_lib, golden_dir, fast):
+    """Symmetric instances (tests/golden/micro_*.npz) produce events with several groups at different locations; both
+    persistent kernels must order them like np.unique(axis=0) under the random policy too (checked against the oracle)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    if fast:
+        os.environ["DCM_FAST_ROLLOUT"] = "1"
+    try:
+        for name in ("micro_ties4", "micro_ties2y", "micro_ties_mixed"):
+            tr = H.load_trace(os.path.join(golden_dir, name + ".npz"))
+            A, T, B = int(tr["A"]), int(tr["T"]), 16
+            env = BatchedTaskEnv(B, A, T, device=gpu_device)
+            env.load_instances(np.repeat(tr["depot"][None], B, 0), np.repeat(tr["task_xy"][None], B, 0),
+                               np.repeat(tr["req"][None], B, 0), np.repeat(tr["dur"][None], B, 0))
+            seeds = env_seeds(77, 0, B)
+            env.reset(seeds, observe=False)
+            steps = env.rollout_random(1).cpu().numpy()
+            fin = H.gpu_final(env)
+            for b in range(B):
+                o = oracle_lib.OracleEnv(A, T).load(tr["depot"], tr["task_xy"], tr["req"], tr["dur"])
+                ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, record=False)
+                assert steps[b] == ref["n_steps"], (name, b)
+                H.assert_final_matches(fin[b], ref, f"{name} env{b} fast={fast}")
+    finally:
+        os.environ.pop("DCM_FAST_ROLLOUT", None)

@@ -86,7 +86,7 @@ def test_golden_traces_protocol(gpu_device, shape):
         name, tr = traces[b]
         if "_random_" in name:
             return H.host_random_action(mask, int(tr["seed_e"]), i)
-        return int(tr["action"][i])
+        return int(tr["action"][i])   # nearest / first-valid / micro scenarios: recorded actions
 
     got = H.run_lockstep(env, seeds, policy)
     fin = H.gpu_final(env)

@@ -23,7 +23,7 @@ ALL_KEYS = ("leader", "action", "nfol", "followers", "now", "mask", "agents_obs"
 def test_full_trace_bit_exact(oracle_lib, path):
     tr = H.load_trace(path)
     A, T = int(tr["A"]), int(tr["T"])
-    pol = os.path.basename(path).split("_")[2]
+    pol = H.trace_policy(path)
     e = oracle_lib.OracleEnv(A, T).load(tr["depot"], tr["task_xy"], tr["req"], tr["dur"])
     out = e.rollout(int(tr["seed_e"]), 0, POLICY[pol], cap_steps=4096)
     assert out["n_steps"] == int(tr["n_steps"])
@@ -33,7 +33,7 @@ def test_full_trace_bit_exact(oracle_lib, path):
         assert np.array_equal(np.asarray(out[k]), tr[k]), k
 
 
-@pytest.mark.parametrize("path", [p for p in H.full_traces() if "20A50T" in p or "5A8T" in p], ids=os.path.basename)
+@pytest.mark.parametrize("path", [p for p in H.full_traces() if "20A50T" in p or "5A8T" in p or "micro_" in p], ids=os.path.basename)
 def test_injected_replay_equals_protocol(oracle_lib, path):
     """Replaying the recorded (leader, followers, action) by injection gives the same episode as drawing them."""
     tr = H.load_trace(path)
@@ -143,5 +143,18 @@ def test_choice_protocol_mirrors(oracle_lib):
 
 def test_quirks_are_exercised(golden_dir):
     q = json.load(open(os.path.join(golden_dir, "manifest.json")))["quirks_in_traces"]
-    assert q["Q2_stale_member_decides"] > 0 and q["Q3_stale_status_masked"] > 0
-    assert q["Q4_rejoin"] > 0 and q["Q7_over_max_time"] > 0
+    assert q["Q1_skip_after_removal"] > 0 and q["Q2_stale_member_decides"] > 0 and q["Q3_stale_status_masked"] > 0
+    assert q["Q4_rejoin"] > 0 and q["Q7_over_max_time"] > 0 and q["multi_group_events"] > 0
+
+
+def test_micro_ties_have_several_groups(oracle_lib, golden_dir):
+    """micro_ties4: four agents finish four symmetric tasks at the same instant -> one event, four groups in
+    ascending (x, y) order (np.unique(axis=0), env/task_env.py:293)."""
+    tr = H.load_trace(os.path.join(golden_dir, "micro_ties4.npz"))
+    e = oracle_lib.OracleEnv(4, 8).load(tr["depot"], tr["task_xy"], tr["req"], tr["dur"])
+    for a, act in enumerate((1, 2, 3, 4)):          # tasks at (0.75,0.5), (0.5,0.75), (0.25,0.5), (0.5,0.25)
+        e.agent_step(a, act)
+    e.task_update(); e.agent_update()
+    ids, t = e.next_decision()
+    assert list(ids) == [0, 1, 2, 3] and t == 0.25 / 0.2 + 5.0
+    assert e.get_unique_group(ids) == [[2], [3], [1], [0]]
