@@ -54,6 +54,25 @@ def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
                        f"{cores} threads, one env per thread")
 
 
+def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
+    """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
+    decision: measured at a batch that fills the machine, HIP events around dcm_step only, device-side random policy."""
+    env = BatchedTaskEnv(B, A, T, device=str(dev)).load_instances(**generate_batch(B, A, T, base_seed=0))
+    obs = env.reset(env_seeds(0, 0, B))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n):
+        act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()
+        ev[i][0].record()
+        obs = env.step(act)
+        ev[i][1].record()
+    torch.cuda.synchronize(dev)
+    ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+    Wb = algorithmic_bytes_per_step(A, T)
+    return {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
+            "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+            "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +82,7 @@ def main():
     ap.add_argument("--agents", type=int, default=20)
     ap.add_argument("--tasks", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
     args = ap.parse_args()
 
@@ -140,6 +160,8 @@ def main():
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inst, seeds, A)
+    if ctx.world == 1 and not args.no_lockstep_probe:
+        out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)
     print(json.dumps(out), flush=True)
     ctx.shutdown()
 
