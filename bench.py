@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/sec of the batched coalition-formation + routing rollout (BASELINE.json metric).
 
-One bench "step" = one pass of the hot path over one batch: every env of the batch plays one complete
-episode under the uniform-random valid policy inside the persistent HIP kernel (dcm_rollout_random), with the
-observation tensors + mask built and stored at every decision.  value = decisions taken by all envs on all
+One bench "step" = one pass of the hot path over one batch: every env of the batch plays 3 consecutive complete
+episodes (auto-reset to the same instance, the decision counter keeps running) under the
+uniform-random valid policy inside ONE launch of the persistent HIP kernel (dcm_rollout_random), with the observation
+tensors + mask built and stored at every decision.  value = decisions taken by all envs on all
 ranks / wall time, inputs (instances, seeds, state) resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -76,11 +77,13 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=20)
     ap.add_argument("--tasks", type=int, default=50)
+    ap.add_argument("--episodes", type=int, default=3,
+                    help="consecutive episodes per env per pass (SURVEY.md §8d config 2: 3, auto-reset to the same instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
@@ -98,7 +101,7 @@ def main():
     env.reset(seeds, observe=False)
 
     def one_pass():
-        steps = env.rollout_random(episodes=1, write_obs=not args.no_obs)
+        steps = env.rollout_random(episodes=args.episodes, write_obs=not args.no_obs)
         if ctx.world > 1:
             ctx.all_gather_returns(env.summary()[:, 0])
         return steps
@@ -114,7 +117,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         ev0[k].record()
-        steps = env.rollout_random(episodes=1, write_obs=not args.no_obs)
+        steps = env.rollout_random(episodes=args.episodes, write_obs=not args.no_obs)
         ev1[k].record()
         if ctx.world > 1:   # per-episode return exchange; overlaps with the next pass (nothing depends on it)
             pending.append(ctx.all_gather_returns(env.summary()[:, 0].contiguous(), async_op=True))
@@ -152,7 +155,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{B} envs/GPU x {A}A/{T}T random-policy rollout, HIP env only (BASELINE configs[1])",
-                   "envs_per_gpu": B, "agents": A, "tasks": T, "episodes_per_step": 1,
+                   "envs_per_gpu": B, "agents": A, "tasks": T, "episodes_per_step": args.episodes,
                    "decisions_per_step_per_gpu": local_steps / K, "sharding": f"env batch x{ctx.world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
                      "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic, "kernel": "k_rollout_random",

@@ -7,7 +7,7 @@ REPO=$(pwd)
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-lockstep-probe"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
