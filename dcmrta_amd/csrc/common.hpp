@@ -39,6 +39,10 @@ constexpr uint32_t A_RETURNED = 1u, A_ASSIGNED = 2u, A_INDEPOT = 4u, A_MEMBER = 
 constexpr uint32_t T_FEAS = 1u << 24, T_FIN = 1u << 25;
 
 __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+// Abandonment log: for every agent the task ids whose abandoned_agent list it was appended to (env/task_env.py:265,271),
+// in event order, up to AB_CAP per episode.  Lives in an HBM side table (touched only by the rare removal path and by the
+// terminal metrics), so calculate_waiting_time's per-agent sums (:358-364) can be accumulated in the reference's order.
+constexpr int AB_CAP = 16;
 // Record layout as a function of (A,T); see DESIGN.md §3.  All sections 8-byte aligned.
 struct Lay {
     int A, T;
@@ -63,7 +67,12 @@ struct Lay {
     __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
     __host__ __device__ constexpr uint32_t tw() const { return rec_bytes(); }        // scratch f64[T] (LDS only)
     __host__ __device__ constexpr uint32_t aw() const { return rec_bytes() + 8 * T; }  // scratch f64[A]
-    __host__ __device__ constexpr uint32_t lds_bytes() const { return align16(rec_bytes() + 8 * T + 8 * A); }
+    __host__ __device__ constexpr uint32_t aux() const { return align16(rec_bytes() + 8 * T + 8 * A); }  // 16 B: side-table pointer
+    __host__ __device__ constexpr uint32_t absort() const { return aux() + 16; }     // scratch u16[A][AB_CAP]
+    __host__ __device__ constexpr uint32_t tmx() const { return align16(absort() + 2 * AB_CAP * A); }   // scratch f64[T]
+    __host__ __device__ constexpr uint32_t twords() const { return (uint32_t)(T + 63) / 64; }
+    __host__ __device__ constexpr uint32_t amask() const { return tmx() + 8 * T; }                       // scratch u64[A][twords]
+    __host__ __device__ constexpr uint32_t lds_bytes() const { return align16(amask() + 8 * A * twords()); }
 };
 static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
 
@@ -252,6 +261,7 @@ struct dcm_env {
     dcm::KP kp;
     unsigned char* state = nullptr;  // [B][rec_bytes]
     double* summary = nullptr;       // [B][8]
+    uint16_t* ablog = nullptr;       // [B][A][AB_CAP] abandonment log (side table of the state)
     bool loaded = false, reset_done = false;
     // route replay (dcmrta_replay.hip)
     int32_t* routes = nullptr;       // [B][A][route_cap] actions

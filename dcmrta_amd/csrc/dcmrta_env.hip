@@ -80,6 +80,14 @@ struct Sim {
     __device__ __forceinline__ double* tdur() const { return (double*)(base + L().tdur()); }
     __device__ __forceinline__ double* tw() const { return (double*)(base + L().tw()); }
     __device__ __forceinline__ double* aw() const { return (double*)(base + L().aw()); }
+    __device__ __forceinline__ uint16_t* absort() const { return (uint16_t*)(base + L().absort()); }
+    __device__ __forceinline__ double* tmx() const { return (double*)(base + L().tmx()); }
+    __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(base + L().amask()); }
+    // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
+    __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + L().aux()); }
+    __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int lane) const {
+        if (lane == 0) *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * A() * AB_CAP;
+    }
 
     struct AMask { uint64_t w[NAW]; };
     __device__ __forceinline__ static int am_count(const AMask& m) { int n = 0;
@@ -170,7 +178,8 @@ struct Sim {
                         const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
                         if (drop & (1u << j)) {
                             // abandoned_agent.append(member) :265/:271; the agent stops being listed at `t`
-                            atomicAdd(&ainfo()[id], 1u << 16);
+                            const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;
+                            if (nth < (uint32_t)AB_CAP) ablog()[id * AB_CAP + nth] = (uint16_t)t;
                             if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
                         } else {
                             nids |= (uint64_t)id << (8 * k);
@@ -226,53 +235,92 @@ struct Sim {
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
     __device__ void compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A();
+        const int TW = (int)L().twords();
+#ifdef DCM_PROFILE_PHASES
+        const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
+        for (int i = lane; i < A_ * TW; i += WAVE) amask()[i] = 0ull;         // per agent: bitmask of the tasks listing it
+        WSYNC();
         for (int t = lane; t < T_; t += WAVE) {
             const uint32_t info = tinfo()[t];
             const int n = (info >> 16) & 0xFF;
             const double ab = (double)tnab()[t] * mwt;
-            double s = 0.;
+            double s = 0., mx = 0.;
             if (n != 0) {                                                    // :349
-                double mx = marr()[t];
+                mx = marr()[t];
                 for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
                 if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - marr()[j * T_ + t]; }   // :351
                 else { for (int j = 0; j < n; j++) s += now - marr()[j * T_ + t]; }               // :354
             }
             tw()[t] = s + ab;                                                // :351-357
+            tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
+            const uint64_t ids = mids()[t];
+            for (int j = 0; j < n; j++)                                      // transpose members -> per-agent task set
+                atomicOr(&amask()[(int)((ids >> (8 * j)) & 0xFF) * TW + (t >> 6)], 1ull << (t & 63));
         }
-        // :358-364 per agent in task order.  The +max_waiting_time terms of abandoned entries are added as
-        // count*mwt after the member terms (the reference interleaves them in task order): equal to within
-        // a few ulp, see DESIGN.md "documented deviation".  Membership: SWAR byte search in the packed id word.
+#ifdef DCM_PROFILE_PHASES
+        const unsigned long long pt1 = __builtin_readcyclecounter();
+        if (lane == 0) atomicAdd(&g_phase_cycles[12], pt1 - pt0);
+#endif
+        // :358-364 per agent, accumulated in the reference's order: tasks ascending; for each task first the member
+        // term, then +max_waiting_time once per entry of the agent in that task's abandoned_agent list.  The entries
+        // come from the abandonment log (event order), sorted here by task id; entries beyond AB_CAP per episode
+        // (never seen) would be added as count*mwt at the end.  Membership: SWAR byte search in the packed id word.
+        {   // bring this env's rows of the side table (A x 32 B, contiguous) into LDS with one coalesced pass
+            const uint4* src = (const uint4*)ablog();
+            uint4* dst = (uint4*)absort();
+            for (int i = lane; i < A_ * AB_CAP * 2 / 16; i += WAVE) dst[i] = src[i];
+        }
+        WSYNC();
         for (int a = lane; a < A_; a += WAVE) {
+            const uint32_t nab = ainfo()[a] >> 16;
+            const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+            uint16_t* my = absort() + a * AB_CAP;
+            for (int i = 1; i < nl; i++) {                                   // in-place insertion sort by task id
+                const uint16_t v = my[i];
+                int j = i;
+                while (j > 0 && my[j - 1] > v) { my[j] = my[j - 1]; j--; }
+                my[j] = v;
+            }
+            int p = 0;
             double s = 0.;
             const uint64_t pat = 0x0101010101010101ull * (uint64_t)(uint32_t)a;
-            for (int t = 0; t < T_; t++) {
-                const uint32_t info = tinfo()[t];
-                const int n = (info >> 16) & 0xFF;
-                const uint64_t x = mids()[t] ^ pat;
-                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-                z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
-                if (z) {
+            // merge, in ascending task id, the tasks that list the agent (member term) with its abandonment entries
+            for (int w = 0; w < TW; w++) {
+                uint64_t m = amask()[a * TW + w];
+                const int wend = (w + 1) * 64;
+                for (;;) {
+                    const int tm = m ? (w * 64 + __ffsll((unsigned long long)m) - 1) : wend;
+                    if (p < nl && (int)my[p] < tm) { s += mwt; p++; continue; }   // :363-364 of an earlier task
+                    if (!m) break;
+                    m &= m - 1;
+                    const uint32_t info = tinfo()[tm];
+                    const int n = (info >> 16) & 0xFF;
+                    const uint64_t x = mids()[tm] ^ pat;
+                    uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                    z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
                     const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
-                    const double mine = marr()[pos * T_ + t];
-                    if (info & T_FEAS) {
-                        double mx = marr()[t];
-                        for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
-                        s += mx - mine;                                      // :360
-                    } else {
-                        const double w = now - mine;
-                        s += (w > 0.) ? w : 0.;                              // :362
-                    }
+                    const double mine = marr()[pos * T_ + tm];
+                    const double wv = now - mine;
+                    s += (info & T_FEAS) ? (tmx()[tm] - mine) : ((wv > 0.) ? wv : 0.);   // :360 / :362
                 }
             }
-            s += (double)(ainfo()[a] >> 16) * mwt;                           // :363-364
+            s += (double)(nab - (uint32_t)nl) * mwt;
             aw()[a] = s;
         }
+#ifdef DCM_PROFILE_PHASES
+        if (lane == 0) atomicAdd(&g_phase_cycles[13], __builtin_readcyclecounter() - pt1);
+#endif
         WSYNC();
     }
 
     // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
     // (header fields are passed by value: a by-reference Hdr would force the caller's header into scratch memory)
+#ifdef DCM_INLINE_TERMINAL
+    __device__ __forceinline__ void terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
+#else
     __device__ __noinline__ void terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
+#endif
         WSYNC();
         compute_waits(now, mwt, lane);
         const int T_ = T(), A_ = A();
@@ -282,11 +330,17 @@ struct Sim {
             nfin += __popcll(__ballot(t < T_ && (tinfo()[t < T_ ? t : 0] & T_FIN)));
         }
         // :422 check_finished() once more can only re-assign the same `now`
+#ifdef DCM_PROFILE_PHASES
+        const unsigned long long pt2 = __builtin_readcyclecounter();
+#endif
         const double Td = (double)T_, Ad = (double)A_;
         const double m2 = psum<4>(ts(), T_) / Td;      // np.nanmean(time_start)      worker.py:105
         const double m3 = psum<4>(aw(), A_) / Ad;      // np.mean(agent sum_waiting)  :106
         const double m4 = psum<4>(tdist(), A_);        // np.sum(travel_dist)         :107
         const double m5 = psum<4>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
+#ifdef DCM_PROFILE_PHASES
+        if (lane == 0) atomicAdd(&g_phase_cycles[14], __builtin_readcyclecounter() - pt2);
+#endif
         if (lane == 0 && row) {
             row[0] = -now;                             // reward, env/task_env.py:424
             row[1] = (double)nfin;
@@ -296,7 +350,13 @@ struct Sim {
         }
     }
     __device__ __forceinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+#ifdef DCM_PROFILE_PHASES
+        const unsigned long long pt = __builtin_readcyclecounter();
+#endif
         terminal_metrics(h.now, P.mwt, lane, row);
+#ifdef DCM_PROFILE_PHASES
+        if (lane == 0) atomicAdd(&g_phase_cycles[15], __builtin_readcyclecounter() - pt);
+#endif
         h.flags |= DCM_FLAG_DONE;
         if (lane == 0) ((Hdr*)base)->episodes += 1;   // cold header fields stay in the LDS record
         h.cur_group = 0;
@@ -673,13 +733,14 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned 
 
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned char* state, const uint64_t* seeds,
-                                               double* summary) {
+                                               double* summary, uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
+    S.set_ablog(ablog, e, lane);
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
@@ -726,13 +787,15 @@ template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char* state, const int32_t* actions,
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
-                                              int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log) {
+                                              int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
+                                              uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     using AMask = typename Sim<CA, CT>::AMask;
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -775,13 +838,14 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
-                                                        int64_t* steps_out, double* summary) {
+                                                        int64_t* steps_out, double* summary, uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     using AMask = typename Sim<CA, CT>::AMask;
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
@@ -834,11 +898,12 @@ __global__ __launch_bounds__(WAVE) void k_env_status(int A, int T, const unsigne
 __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
-                                                   int32_t* n_abandoned) {
+                                                   int32_t* n_abandoned, uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<0, 0> S{A, T, smem};
     const Lay L = S.L();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
@@ -859,11 +924,12 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned
 __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
-                                                    int32_t* current, int32_t* pending) {
+                                                    int32_t* current, int32_t* pending, uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<0, 0> S{A, T, smem};
     const Lay L = S.L();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
@@ -930,14 +996,17 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     const size_t bytes = (size_t)params->n_envs * h->L.rec_bytes();
     hipError_t e1 = hipMalloc((void**)&h->state, bytes);
     hipError_t e2 = hipMalloc((void**)&h->summary, (size_t)params->n_envs * 8 * sizeof(double));
+    if (e1 == hipSuccess && e2 == hipSuccess)
+        e2 = hipMalloc((void**)&h->ablog, (size_t)params->n_envs * params->n_agents * AB_CAP * sizeof(uint16_t));
     if (e1 != hipSuccess || e2 != hipSuccess) {
         if (h->state) (void)hipFree(h->state);
         if (h->summary) (void)hipFree(h->summary);
+        if (h->ablog) (void)hipFree(h->ablog);
         delete h;
         return fail(DCM_ERR_HIP, "dcm_create: hipMalloc failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     hipError_t e3 = hipMemset(h->state, 0, bytes);
-    if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
+    if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); (void)hipFree(h->ablog); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
     // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS
     const int lds = (int)h->L.lds_bytes();
 #define SET_ATTR(CA, CT)                                                                                             \
@@ -960,6 +1029,7 @@ int dcm_destroy(dcm_env* env) {
     (void)hipSetDevice(env->p.device);
     if (env->state) (void)hipFree(env->state);
     if (env->summary) (void)hipFree(env->summary);
+    if (env->ablog) (void)hipFree(env->ablog);
     if (env->routes) (void)hipFree(env->routes);
     if (env->route_len) (void)hipFree(env->route_len);
     delete env;
@@ -985,7 +1055,7 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT)                                                                                                  \
     hipLaunchKernelGGL((k_reset<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
-                       env->state, seeds, env->summary)
+                       env->state, seeds, env->summary, env->ablog)
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1028,7 +1098,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
 #define CALL(CA, CT)                                                                                                 \
     hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary, env->log)
+                       active_out, env->summary, env->log, env->ablog)
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1042,10 +1112,10 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, float* agents_out, float*
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
 #define CALL(CA, CT)                                                                                                  \
     hipLaunchKernelGGL((k_rollout_random<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, \
-                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary)
+                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog)
 #define CALL_FAST(CA, CT)                                                                                             \
     hipLaunchKernelGGL((k_rollout_fast<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,  \
-                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary)
+                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog)
     if (env->L.A <= 64 && env->L.T <= 64 && getenv("DCM_FAST_ROLLOUT")) {
         // opt-in register-resident kernel: lane t owns task t, lane a owns agent a (fast_rollout.hpp); parity-green but
         // measured 3 % slower than the LDS-resident kernel at 20A/50T (0.695 vs 0.675 ms/launch), so not the default
@@ -1080,7 +1150,8 @@ int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* ti
                   double* sum_wait, int32_t* status, int32_t* n_members, int32_t* n_abandoned, void* stream) {
     CHECK_ENV(env);
     hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
-                       env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned);
+                       env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned,
+                       env->ablog);
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1091,7 +1162,7 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
     CHECK_ENV(env);
     hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
-                       pending_group);
+                       pending_group, env->ablog);
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1099,7 +1170,8 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
 int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_ENV(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
-    *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double);
+    *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double) +
+                 (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t);
     return DCM_OK;
 }
 
@@ -1108,7 +1180,9 @@ int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
     if (!dst) return fail(DCM_ERR_INVALID, "dcm_clone_state: null dst");
     const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(dst, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb, env->summary, (size_t)env->p.n_envs * 8 * sizeof(double),
+    const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
+    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb, env->summary, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb + mb, env->ablog, (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DCM_OK;
 }
@@ -1118,8 +1192,10 @@ int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
     if (!src) return fail(DCM_ERR_INVALID, "dcm_restore_state: null src");
     const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(env->state, src, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync(env->summary, (const unsigned char*)src + sb, (size_t)env->p.n_envs * 8 * sizeof(double),
-                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(env->summary, (const unsigned char*)src + sb, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(env->ablog, (const unsigned char*)src + sb + mb,
+                           (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     env->loaded = true;
     env->reset_done = true;
     return DCM_OK;

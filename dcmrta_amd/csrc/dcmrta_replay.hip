@@ -380,7 +380,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
                 s += mx - mine;                                              // :360
             } else { const double w = now - mine; s += (w > 0.0) ? w : 0.0; }   // :362
         }
-        s += (double)(R.ainfo()[a] >> 16) * mwt;                             // :363-364 (count * mwt, DESIGN.md deviation)
+        s += (double)(R.ainfo()[a] >> 16) * mwt;                             // :363-364 as count * mwt (replay mode)
         R.aw()[a] = s;
     }
     WSYNC();

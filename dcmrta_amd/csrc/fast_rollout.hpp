@@ -94,7 +94,7 @@ struct Fast {
     // ------------------------------------------------------------------------------ task_update (env/task_env.py:245-281)
     // rare path: some task removes members (:262-265 spread, :268-271 expiry).  Compacts the survivors in order on the
     // owning lane and books the abandonment on the agents' lanes.
-    __device__ __forceinline__ static void drop_members(St& s, uint32_t drop, int lane) {
+    __device__ __forceinline__ static void drop_members(St& s, const S_t& S, uint32_t drop, int lane) {
         uint64_t dl = __ballot(drop != 0);
         while (dl) {                                       // agents' side, one dropping task at a time (wave-uniform)
             const int t = __ffsll((unsigned long long)dl) - 1;
@@ -105,6 +105,8 @@ struct Fast {
             for (int j = 0; j < M; j++) if (dm & (1u << j)) {
                 const int id = (int)((ids >> (8 * j)) & 0xFF);
                 if (lane == id) {                          // abandoned_agent.append(member) :265/:271
+                    const uint32_t nth = s.ainfo >> 16;
+                    if (nth < (uint32_t)AB_CAP) S.ablog()[id * AB_CAP + nth] = (uint16_t)t;
                     s.ainfo += 1u << 16;
                     if (s.cur == t) s.ainfo &= ~A_MEMBER;
                 }
@@ -133,7 +135,7 @@ struct Fast {
         }
     }
 
-    __device__ __forceinline__ static void task_update(St& s, double now, double mwt, int lane) {
+    __device__ __forceinline__ static void task_update(St& s, const S_t& S, double now, double mwt, int lane) {
         const uint32_t info0 = s.tinfo;
         const bool feas0 = info0 & T_FEAS;
         const int req = info0 & 0xFF, n = (info0 >> 16) & 0xFF;               // :250
@@ -159,7 +161,7 @@ struct Fast {
         s.tf = ok ? mx + s.tdur : s.tf;                                       // :257
         const uint32_t upd = (info0 & (T_FIN | 0x00FF00FFu)) | (ok ? T_FEAS : 0u) | ((uint32_t)(status & 0xFF) << 8);
         s.tinfo = feas0 ? (info0 | (fin ? T_FIN : 0u)) : upd;
-        if (__any(drop != 0)) drop_members(s, drop, lane);
+        if (__any(drop != 0)) drop_members(s, S, drop, lane);
         const bool all_feasible = __all(s.tinfo & T_FEAS);
         const bool ret = (s.ainfo & A_INDEPOT) && all_feasible && (now >= s.arr);   // depot :277-280
         s.ainfo |= ret ? A_RETURNED : 0u;
@@ -345,13 +347,14 @@ struct Fast {
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, KP P, unsigned char* state, int episodes,
                                                       float* agents_out, float* tasks_out, uint8_t* mask_out,
-                                                      int64_t* steps_out, double* summary) {
+                                                      int64_t* steps_out, double* summary, uint16_t* ablog) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     using F = Fast<CA, CT>;
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, KP P, un
                 if (h.flags & DCM_FLAG_DONE) break;
                 steps++;
             }
-            F::task_update(s, h.now, P.mwt, lane);                            // worker.py:74 / :50
+            F::task_update(s, S, h.now, P.mwt, lane);                         // worker.py:74 / :50
             F::agent_update(s, h.now, P.mwt);                                 // worker.py:76 / :51
             if (deciding) {
                 if (rlen > 0) continue;                                       // worker.py:53 same group, next leader

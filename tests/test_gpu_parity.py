@@ -150,9 +150,8 @@ def test_multi_episode_rollout(gpu_device, golden_dir):
         sm = env.summary().cpu().numpy()[0]
         assert steps == ep["n_steps"]
         assert sm[0] == ep["reward"] and int(sm[1]) == ep["n_finished"]
-        for i in (0, 1, 2, 4, 5):
+        for i in range(6):
             assert sm[2 + i] == ep["metrics"][i]
-        np.testing.assert_allclose(sm[5], ep["metrics"][3], rtol=1e-12)
         total += steps
     # the same three episodes in ONE launch
     env.reset(np.array([int(man["seed_e"])], np.uint64), observe=False)

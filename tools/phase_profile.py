@@ -38,4 +38,6 @@ names = ["leader", "observe", "action", "apply(move+slots)", "task_update#1", "a
 tot = sum(buf[i] for i in range(12))
 print(f"{n} decisions, {tot / n:.0f} wave-cycles (s_memtime) per decision")
 for i, nm in enumerate(names):
-    print(f"  {nm:22s} {buf[i] / n:8.1f} cyc/decision  {100.0 * buf[i] / tot:5.1f} %")
+    print(f"  {nm:22s} {buf[i] / n:8.1f} cyc/decision  {100.0 * buf[i] / max(tot, 1):5.1f} %")
+for i, nm in ((12, "terminal: task waits"), (13, "terminal: agent waits"), (14, "terminal: pairwise sums"), (15, "terminal: whole call")):
+    print(f"  {nm:22s} {buf[i] / n:8.1f} cyc/decision  (inside advance:tail)")
