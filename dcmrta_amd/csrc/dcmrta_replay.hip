@@ -42,9 +42,10 @@ struct RLay {
     __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
     __device__ uint32_t tnab() const { return tinfo() + 4 * T; }           // u32[T]
     __device__ uint32_t mid() const { return tnab() + 4 * T; }             // u8[MR][T]
+    __device__ uint32_t ablog() const { return align16(mid() + MR * T); }  // u16[A][AB_CAP] abandonment log
 };
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16((uint32_t)(64 * A + 48 * T + 8 * MR * T + 8 * T + MR * T));
+    return align16(align16((uint32_t)(64 * A + 48 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
 }
 
 struct RP {
@@ -85,6 +86,7 @@ struct Rep {
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
     __device__ uint32_t* tnab() const { return (uint32_t*)(b + L.tnab()); }
     __device__ uint8_t* mid() const { return (uint8_t*)(b + L.mid()); }
+    __device__ uint16_t* ablog() const { return (uint16_t*)(b + L.ablog()); }
 
     // tinfo[t]: bits 0-7 requirements, 8-15 status (int8), 16-23 len(members), 24 feasible, 25 finished
 
@@ -124,7 +126,8 @@ struct Rep {
                             if (k != j) { mid()[k * T + t] = (uint8_t)id; marr()[k * T + t] = marr()[j * T + t]; }
                             k++;
                         } else {
-                            atomicAdd(&ainfo()[id], 1u << 16);               // abandoned_agent.append :265/:271
+                            const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
+                            if (nth < (uint32_t)AB_CAP) ablog()[id * AB_CAP + nth] = (uint16_t)t;
                             if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
                         }
                     }
@@ -365,22 +368,36 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         }
         R.tw()[t] = s + ab;
     }
+    // :358-364 per agent in the reference's order: tasks ascending, member term first, then +max_waiting_time per
+    // entry of the agent in that task's abandoned_agent list (entries from the abandonment log, sorted by task id)
     for (int a = lane; a < A; a += WAVE) {
+        const uint32_t nab = R.ainfo()[a] >> 16;
+        const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+        uint16_t* my = R.ablog() + a * AB_CAP;
+        for (int i = 1; i < nl; i++) {
+            const uint16_t v = my[i];
+            int j = i;
+            while (j > 0 && my[j - 1] > v) { my[j] = my[j - 1]; j--; }
+            my[j] = v;
+        }
+        int p = 0;
         double s = 0.0;
         for (int t = 0; t < T; t++) {
             const uint32_t info = R.tinfo()[t];
             const int n = (info >> 16) & 0xFF;
             int pos = -1;
             for (int j = 0; j < n; j++) if (R.mid()[j * T + t] == a) pos = j;
-            if (pos < 0) continue;
-            const double mine = R.marr()[pos * T + t];
-            if (info & T_FEAS) {
-                double mx = R.marr()[t];
-                for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
-                s += mx - mine;                                              // :360
-            } else { const double w = now - mine; s += (w > 0.0) ? w : 0.0; }   // :362
+            if (pos >= 0) {
+                const double mine = R.marr()[pos * T + t];
+                if (info & T_FEAS) {
+                    double mx = R.marr()[t];
+                    for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
+                    s += mx - mine;                                          // :360
+                } else { const double w = now - mine; s += (w > 0.0) ? w : 0.0; }   // :362
+            }
+            while (p < nl && my[p] == (uint16_t)t) { s += mwt; p++; }        // :363-364
         }
-        s += (double)(R.ainfo()[a] >> 16) * mwt;                             // :363-364 as count * mwt (replay mode)
+        s += (double)(nab - (uint32_t)nl) * mwt;
         R.aw()[a] = s;
     }
     WSYNC();
