@@ -41,7 +41,8 @@ def _ptr(t):
 
 
 class BatchedTaskEnv:
-    def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0):
+    def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
+                 individual_selection=False):
         self._h = None
         self._lib = _lib.load()
         self.device = torch.device(device)
@@ -53,7 +54,8 @@ class BatchedTaskEnv:
         self.max_waiting_time, self.max_time = float(max_waiting_time), float(max_time)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
-        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, 0, 0)
+        # individual_selection: Worker.run_test_IS (worker.py:159-198) -- deciders are not grouped by location
+        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, 1 if individual_selection else 0, 0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self._lib.dcm_create(C.byref(p), C.byref(h)))

@@ -366,7 +366,10 @@ struct Sim {
     // Boxes D + A of SURVEY.md Appendix B: check_finished (worker.py:85, env/task_env.py:366-373), loop test
     // (worker.py:45), next_decision (:283-289), get_unique_group (:291-298), task_update, agent_update
     // (worker.py:50-51).  Returns at the next decision point or after terminal().
-    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS) const {
+    // no_grouping: every deciding agent forms ONE group (individual selection, worker.py:159-198 iterates the deciders without
+    // get_unique_group); lockstep API only.
+    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
+                                            bool no_grouping = false) const {
         const int A_ = A(), T_ = T();
         for (;;) {
             WSYNC();
@@ -418,7 +421,7 @@ struct Sim {
                     px[i] = ax()[a < A_ ? a : 0]; py[i] = ay()[a < A_ ? a : 0];
                     same = same && (!dec[i] || (px[i] == x0 && py[i] == y0));
                 }
-                if (__all(same)) {
+                if (no_grouping || __all(same)) {
 #pragma unroll
                     for (int i = 0; i < NAW; i++) {
                         const int a = i * 64 + lane;
@@ -588,7 +591,8 @@ struct Sim {
     __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
-                                                      const RouteLog* log = nullptr, int env_index = 0) const {
+                                                      const RouteLog* log = nullptr, int env_index = 0,
+                                                      bool no_grouping = false) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         AMask rest = gm0;
@@ -601,7 +605,7 @@ struct Sim {
         uint64_t mlist = (uint64_t)(uint32_t)leader;                          // ordered member ids, byte j (task actions only)
         int nm = 1;
         double tx_, ty_;
-        if (action == 0) {
+        if (action == 0 && nfol_in < 0) {
             // vacancy = len(group) (:327): every co-located agent returns with the leader (Q9); the draw
             // order of the followers cannot change any state, so no draws are spent.
 #pragma unroll
@@ -610,9 +614,12 @@ struct Sim {
             tx_ = ((const Hdr*)base)->depot_x; ty_ = ((const Hdr*)base)->depot_y;
         } else {
             const int k = action - 1;
-            const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
-            int nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
-            if (nfol_in >= 0) nf = nfol_in;
+            int nf;
+            if (nfol_in >= 0) nf = nfol_in;                                   // injected (also for the depot: individual selection)
+            else {
+                const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
+                nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
+            }
             if (nf > M - 1 || nf > rlen) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                    // :331 choice without replacement
@@ -630,8 +637,10 @@ struct Sim {
                 mlist |= (uint64_t)(uint32_t)f << (8 * nm);
                 nm++;
             }
-            tx_ = tx()[k]; ty_ = ty()[k];
+            if (action == 0) { tx_ = ((const Hdr*)base)->depot_x; ty_ = ((const Hdr*)base)->depot_y; }
+            else { tx_ = tx()[k]; ty_ = ty()[k]; }
         }
+        PH_MARK(11);
         // agent_step for every member (:300-324); independent per agent
         double arrv[NAW];
 #pragma unroll
@@ -699,7 +708,7 @@ struct Sim {
         PH_MARK(5);
         if (rlen > 0) return;                                                 // worker.py:53 same group, next leader
         if (h.cur_group < h.n_groups) { h.cur_group++; return; }              // worker.py:52 next group
-        advance(h, P, lane, row PH_PASS);                                     // worker.py:85 -> :45
+        advance(h, P, lane, row PH_PASS, no_grouping);                        // worker.py:85 -> :45
         PH_MARK(9);
     }
 
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned 
 
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned char* state, const uint64_t* seeds,
-                                               double* summary, uint16_t* ablog) {
+                                               double* summary, uint16_t* ablog, uint32_t mode) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     const Lay L = S.L();
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
     S.reset_state(h, lane);
     if (lane < 8) summary[(size_t)e * 8 + lane] = __builtin_nan("");
     PH_DECL;
-    S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS);
+    S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
@@ -788,7 +797,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
-                                              uint16_t* ablog) {
+                                              uint16_t* ablog, uint32_t mode) {
     const int e = blockIdx.x, lane = threadIdx.x;
     Sim<CA, CT> S{A, T, smem};
     using AMask = typename Sim<CA, CT>::AMask;
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e);
+                                &log, e, (mode & DCM_PARAM_NO_GROUPING) != 0);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -1055,7 +1064,7 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT)                                                                                                  \
     hipLaunchKernelGGL((k_reset<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
-                       env->state, seeds, env->summary, env->ablog)
+                       env->state, seeds, env->summary, env->ablog, env->p.flags)
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1098,7 +1107,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
 #define CALL(CA, CT)                                                                                                 \
     hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary, env->log, env->ablog)
+                       active_out, env->summary, env->log, env->ablog, env->p.flags)
     DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
 #undef CALL
     LAUNCH_OK();

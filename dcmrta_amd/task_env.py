@@ -31,7 +31,7 @@ from .instances import generate_instance
 
 class TaskEnv:
     def __init__(self, agents_range=(10, 10), tasks_range=(10, 10), traits_dim=1, max_coalition_size=3, max_duration=5,
-                 seed=None, plot_figure=False, device="cuda:0", choice_seed=0):
+                 seed=None, plot_figure=False, device="cuda:0", choice_seed=0, individual_selection=False):
         if traits_dim != 1:
             raise NotImplementedError("traits_dim != 1 does not work in the reference either (SURVEY.md §5)")
         if max_coalition_size > _lib.MAX_MEMBERS:
@@ -45,23 +45,28 @@ class TaskEnv:
         task_xy = rng.random((T, 2))
         req = rng.integers(1, max_coalition_size + 1, T).astype(np.int32)
         dur = np.full(T, float(max_duration))
-        self._init_from_arrays(A, depot, task_xy, req, dur, device, choice_seed)
+        self._init_from_arrays(A, depot, task_xy, req, dur, device, choice_seed, individual_selection=individual_selection)
 
     @classmethod
-    def from_arrays(cls, n_agents, depot, task_xy, req, dur, device="cuda:0", choice_seed=0, max_waiting_time=10.0):
+    def from_arrays(cls, n_agents, depot, task_xy, req, dur, device="cuda:0", choice_seed=0, max_waiting_time=10.0,
+                    individual_selection=False):
+        """individual_selection=True: the run_test_IS call pattern (worker.py:159-198) -- deciders are not grouped and act
+        one by one through agent_step()."""
         self = cls.__new__(cls)
         self._init_from_arrays(int(n_agents), np.asarray(depot, np.float64), np.asarray(task_xy, np.float64),
                                np.asarray(req, np.int32), np.asarray(dur, np.float64), device, choice_seed,
-                               max_waiting_time)
+                               max_waiting_time, individual_selection)
         return self
 
-    def _init_from_arrays(self, A, depot, task_xy, req, dur, device, choice_seed, max_waiting_time=10.0):
+    def _init_from_arrays(self, A, depot, task_xy, req, dur, device, choice_seed, max_waiting_time=10.0,
+                          individual_selection=False):
         self.agents_num, self.tasks_num = A, len(req)
         self.max_waiting_time = float(max_waiting_time)
         self.reactive_planning = False
         self.dt = 0.1
         self._inst = (depot.copy(), task_xy.copy(), req.copy(), dur.copy())
-        self._env = BatchedTaskEnv(1, A, self.tasks_num, device=device, max_waiting_time=self.max_waiting_time)
+        self._env = BatchedTaskEnv(1, A, self.tasks_num, device=device, max_waiting_time=self.max_waiting_time,
+                                   individual_selection=individual_selection)
         self._env.load_instances(depot[None], task_xy[None], req[None], dur[None])
         self._seed = np.array([choice_seed], dtype=np.uint64)
         self.depot = {"location": depot.copy(), "members": [], "ID": -1}

@@ -58,6 +58,11 @@ typedef enum {
 #define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
 #define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 
+/* dcm_params.flags: individual selection -- all agents deciding at an event form ONE group in ascending id order and are
+ * meant to be stepped one by one with nfol_in = 0 (Worker.run_test_IS, worker.py:159-198, skips get_unique_group).
+ * Honoured by dcm_reset / dcm_step; dcm_rollout_random always groups by location. */
+#define DCM_PARAM_NO_GROUPING 1u
+
 typedef struct {
     int32_t n_envs;             /* B */
     int32_t n_agents;           /* A, identical for every env of the batch (driver.py:114-117) */
@@ -65,7 +70,7 @@ typedef struct {
     int32_t device;             /* HIP device ordinal */
     double max_waiting_time;    /* env/task_env.py:30 (10) */
     double max_time;            /* MAX_TIME, parameters.py:18 (100) */
-    uint32_t flags;             /* reserved, 0 */
+    uint32_t flags;             /* DCM_PARAM_* bits */
     uint32_t reserved;
 } dcm_params;
 
@@ -103,7 +108,8 @@ int dcm_observe(dcm_env *env, float *agents_out, float *tasks_out, uint8_t *mask
  * (worker.py:45-51) -> terminal (worker.py:87, metrics :103-108).
  *   actions[B] i32: 0 = depot, k = task k-1.
  *   leader_in / nfol_in / followers_in[B,DCM_FOLLOWER_COLS] (all nullable): injected choices;
- *   nfol_in[b] < 0 means "draw followers from the protocol".
+ *   nfol_in[b] < 0 means "draw followers from the protocol"; nfol_in[b] >= 0 is honoured for the depot action too (the
+ *   leader returns with exactly those followers -- agent_step(agent, 0) of individual selection -- instead of the whole group).
  * If agents_out..active_out are non-NULL the observation of the NEW decision point is written
  * in the same launch (fused observe; leader drawn from the protocol). */
 int dcm_step(dcm_env *env, const int32_t *actions, const int32_t *leader_in, const int32_t *nfol_in,

@@ -124,3 +124,48 @@ def test_full_size_properties(gpu_device):
         # a makespan beyond MAX_TIME only through quirk Q7 (the event that crosses 100 is processed completely)
         assert (sm[:, 3] < 100 + 10 + 5 * 2 ** 0.5 + 5).all()
         assert int(s1.min()) > 0
+
+
+def test_individual_selection_mode(gpu_device, oracle_lib):
+    """Worker.run_test_IS (worker.py:159-198): every deciding agent acts alone, in ascending id order, without
+    get_unique_group; greedy "first valid action" policy.  Reference loop restated on the oracle's step-wise surface."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 4, 8, 14
+    inst = generate_batch(B, A, T, base_seed=61)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, individual_selection=True).load_instances(**inst)
+    env.reset(np.arange(B, dtype=np.uint64), observe=False)
+    # device: always inject the lowest pending agent as leader, no followers
+    steps = np.zeros(B, int)
+    for _ in range(2000):
+        pg = env.agents_state()["pending_group"].cpu().numpy()
+        flags = env.status()["flags"].cpu().numpy()
+        if (flags & 1).all():
+            break
+        lead = np.array([int(np.flatnonzero(pg[b] > 0)[0]) if not (flags[b] & 1) else -1 for b in range(B)], np.int32)
+        obs = env.observe(leader=lead)
+        act = torch.argmax((~obs.mask).to(torch.int32), dim=1).int()
+        env.step(act, leader=lead, n_followers=np.zeros(B, np.int32), followers=np.full((B, 4), -1, np.int16), observe=False)
+        steps += (~(flags & 1).astype(bool)).astype(int)
+    fin = H.gpu_final(env)
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        n, finished, guard = 0, False, 0
+        while not finished and o.now < 100:                                  # worker.py:163
+            ids, t = o.next_decision()                                       # :165
+            o.now = t                                                        # :167
+            o.task_update(); o.agent_update()                                # :168-169
+            for a in ids:                                                    # :170
+                m = o.mask()                                                 # :175-179
+                o.agent_step(int(a), int(np.flatnonzero(m == 0)[0]))         # :185-186
+                o.task_update(); o.agent_update()                            # :187-188
+                n += 1
+            finished = o.check_finished()                                    # :189
+            guard += 1
+            assert guard < 5000
+        ref = o.final()
+        from oracle import lib as _ol
+        _ol().orc_finish_episode(o._h)
+        ref = o.final()
+        assert steps[b] == n, (b, steps[b], n)
+        H.assert_final_matches(fin[b], ref, f"IS env{b}")

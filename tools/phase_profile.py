@@ -33,8 +33,8 @@ raw.dcm_prof_read(buf, 1)
 n = int(env.rollout_random(1).sum())
 torch.cuda.synchronize()
 raw.dcm_prof_read(buf, 0)
-names = ["leader", "observe", "action", "apply(move+slots)", "task_update#1", "agent_update#1", "advance:D+groups",
-         "task_update#2", "agent_update#2", "advance:tail", "reset+first event", "-"]
+names = ["leader", "observe", "action", "apply: move+slots", "task_update#1", "agent_update#1", "advance:D+groups",
+         "task_update#2", "agent_update#2", "advance:tail", "reset+first event", "apply: followers+target"]
 tot = sum(buf[i] for i in range(12))
 print(f"{n} decisions, {tot / n:.0f} wave-cycles (s_memtime) per decision")
 for i, nm in enumerate(names):
