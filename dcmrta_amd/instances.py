@@ -24,6 +24,19 @@ def generate_instance(A, T, seed, max_coalition_size=5, max_duration=5.0):
     return dict(depot=depot, task_xy=task_xy, req=req, dur=dur)
 
 
+def generate_instance_ranges(agents_range, tasks_range, seed, max_coalition_size=5, max_duration=5.0):
+    """TaskEnv(agents_range, tasks_range, ...) with tuple ranges: the sizes are drawn first, tasks then agents
+    (env/task_env.py:58-65), from the same seeded stream.  Returns (A, instance dict)."""
+    rng = np.random.default_rng(seed)
+    T = int(rng.integers(tasks_range[0], tasks_range[1] + 1)) if isinstance(tasks_range, tuple) else int(tasks_range)
+    A = int(rng.integers(agents_range[0], agents_range[1] + 1)) if isinstance(agents_range, tuple) else int(agents_range)
+    depot = rng.random((1, 2))[0]
+    rng.random((A, 1))
+    task_xy = rng.random((T, 2))
+    req = rng.integers(1, max_coalition_size + 1, T).astype(np.int32)
+    return A, dict(depot=depot, task_xy=task_xy, req=req, dur=np.full(T, float(max_duration)))
+
+
 def generate_batch(B, A, T, base_seed=0, first=0, max_coalition_size=5, max_duration=5.0):
     """Instances base_seed+first .. base_seed+first+B-1 stacked as depot[B,2], task_xy[B,T,2], req[B,T], dur[B,T]."""
     depot = np.empty((B, 2), np.float64)

@@ -36,15 +36,9 @@ class TaskEnv:
             raise NotImplementedError("traits_dim != 1 does not work in the reference either (SURVEY.md §5)")
         if max_coalition_size > _lib.MAX_MEMBERS:
             raise ValueError(f"max_coalition_size <= {_lib.MAX_MEMBERS}")
-        rng = np.random.default_rng(seed)
-        # env/task_env.py:58-65: sizes are drawn first when ranges are tuples
-        T = int(rng.integers(tasks_range[0], tasks_range[1] + 1)) if isinstance(tasks_range, tuple) else int(tasks_range)
-        A = int(rng.integers(agents_range[0], agents_range[1] + 1)) if isinstance(agents_range, tuple) else int(agents_range)
-        depot = rng.random((1, 2))[0]
-        rng.random((A, 1))
-        task_xy = rng.random((T, 2))
-        req = rng.integers(1, max_coalition_size + 1, T).astype(np.int32)
-        dur = np.full(T, float(max_duration))
+        from .instances import generate_instance_ranges
+        A, inst = generate_instance_ranges(agents_range, tasks_range, seed, max_coalition_size, max_duration)   # :58-71
+        depot, task_xy, req, dur = inst["depot"], inst["task_xy"], inst["req"], inst["dur"]
         self._init_from_arrays(A, depot, task_xy, req, dur, device, choice_seed, individual_selection=individual_selection)
 
     @classmethod

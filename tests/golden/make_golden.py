@@ -462,6 +462,16 @@ def main():
                         n_finished=int(tr["finished"].sum()), metrics=[float(x) for x in tr["metrics"]]))
     manifest["multi_episode"] = dict(inst_seed=7, seed_e=str(se), episodes=eps)
 
+    # instance generation with tuple ranges (sizes drawn from the seeded stream first, env/task_env.py:58-65)
+    rng_inst = {}
+    for sd in range(6):
+        env = TaskEnv((10, 20), (20, 50), 1, 5, seed=sd)   # AGENTS_RANGE / TASKS_RANGE of parameters.py:15-16
+        ia = instance_arrays(env)
+        rng_inst[str(sd)] = dict(A=int(ia["A"]), T=int(ia["T"]), depot=ia["depot"].tolist(), task_xy0=ia["task_xy"][0].tolist(),
+                                 task_xy_last=ia["task_xy"][-1].tolist(), req=ia["req"].tolist())
+    with open(f"{OUT}/instances_ranges.json", "w") as f:
+        json.dump(rng_inst, f)
+
     manifest["quirks_in_traces"] = quirks
     with open(f"{OUT}/manifest.json", "w") as f:
         json.dump(manifest, f, indent=1)

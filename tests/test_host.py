@@ -54,6 +54,8 @@ def test_instance_generator_matches_reference_draw_order(golden_dir):
     from dcmrta_amd.instances import generate_batch, generate_instance
     for p in H.full_traces():
         tr = H.load_trace(p)
+        if int(tr["inst_seed"]) < 0:
+            continue  # hand-built symmetric instances (micro_*.npz)
         g = generate_instance(int(tr["A"]), int(tr["T"]), int(tr["inst_seed"]))
         for k in ("depot", "task_xy", "req", "dur"):
             assert np.array_equal(g[k], tr[k]), (p, k)
@@ -108,3 +110,15 @@ def test_read_ctasd_routes(tmp_path):
     assert read_ctasd_routes(tmp_path / "r.yaml", tmp_path / "p.yaml") == [[3, 1, 0], None, [2, 0]]
     (tmp_path / "r2.yaml").write_text(yaml.dump({"result": {"flagSuccess": 0}}))
     assert read_ctasd_routes(tmp_path / "r2.yaml", tmp_path / "p.yaml") is None
+
+
+def test_instance_generator_with_ranges(golden_dir):
+    """TaskEnv((10,20),(20,50),...,seed=s) of the reference: sizes and arrays (tests/golden/instances_ranges.json)."""
+    import json
+    from dcmrta_amd.instances import generate_instance_ranges
+    ref = json.load(open(os.path.join(golden_dir, "instances_ranges.json")))
+    for sd, r in ref.items():
+        A, inst = generate_instance_ranges((10, 20), (20, 50), int(sd))
+        assert (A, len(inst["req"])) == (r["A"], r["T"])
+        assert inst["depot"].tolist() == r["depot"] and inst["task_xy"][0].tolist() == r["task_xy0"]
+        assert inst["task_xy"][-1].tolist() == r["task_xy_last"] and inst["req"].tolist() == r["req"]
