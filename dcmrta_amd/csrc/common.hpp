@@ -177,7 +177,8 @@ __device__ __forceinline__ double wave_nanmax(double v) {
 // position of the idx-th (0-based) set bit of a wave-uniform mask; all 64 lanes must call
 __device__ __forceinline__ int nth_set_bit(uint64_t m, int idx, int lane) {
     const bool b = (m >> lane) & 1ull;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    // v_mbcnt_lo/hi: number of set bits of m below this lane (two VALU ops, no lane-mask registers)
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const uint64_t sel = __ballot(b && rank == idx);
     return __ffsll((unsigned long long)sel) - 1;
 }

@@ -61,15 +61,16 @@ class BatchedRunner:
     def rollout(self, net, env, seeds, greedy, record):
         B, A, T, dev = env.B, env.A, env.T, env.device
         obs = env.reset(seeds)
-        S = self.max_steps
-        rec = None
-        if record:
-            rec = dict(agents=torch.empty((S, B, A, 6), dtype=torch.float32, device=dev),
-                       tasks=torch.empty((S, B, T + 1, 5), dtype=torch.float32, device=dev),
-                       mask=torch.empty((S, B, T + 1), dtype=torch.bool, device=dev),
-                       action=torch.zeros((S, B), dtype=torch.int64, device=dev),
-                       leader=torch.zeros((S, B), dtype=torch.int64, device=dev),
-                       active=torch.zeros((S, B), dtype=torch.bool, device=dev))
+        S, CH = self.max_steps, 128
+        chunks = []                       # experience is recorded in chunks of CH batched steps, allocated on demand
+
+        def new_chunk():
+            return dict(agents=torch.empty((CH, B, A, 6), dtype=torch.float32, device=dev),
+                        tasks=torch.empty((CH, B, T + 1, 5), dtype=torch.float32, device=dev),
+                        mask=torch.empty((CH, B, T + 1), dtype=torch.bool, device=dev),
+                        action=torch.zeros((CH, B), dtype=torch.int64, device=dev),
+                        leader=torch.zeros((CH, B), dtype=torch.int64, device=dev),
+                        active=torch.zeros((CH, B), dtype=torch.bool, device=dev))
         s = 0
         while True:
             if not bool(obs.active.any()):       # worker.py:45 for every env of the batch
@@ -82,10 +83,16 @@ class BatchedRunner:
             else:
                 action = torch.distributions.Categorical(logits=logp).sample()  # worker.py:70 (probs = logp.exp())
             if record:
-                rec["agents"][s].copy_(obs.agents); rec["tasks"][s].copy_(obs.tasks); rec["mask"][s].copy_(obs.mask)
-                rec["action"][s].copy_(action); rec["leader"][s].copy_(obs.leader); rec["active"][s].copy_(obs.active)
+                if s % CH == 0:
+                    chunks.append(new_chunk())
+                c, i = chunks[-1], s % CH
+                c["agents"][i].copy_(obs.agents); c["tasks"][i].copy_(obs.tasks); c["mask"][i].copy_(obs.mask)
+                c["action"][i].copy_(action); c["leader"][i].copy_(obs.leader); c["active"][i].copy_(obs.active)
             obs = env.step(action.to(torch.int32))                               # worker.py:73-76,85
             s += 1
+        rec = None
+        if record:
+            rec = {k: torch.cat([c[k] for c in chunks])[:max(s, 1)] for k in chunks[0]} if chunks else None
         summary = env.summary()                                                  # worker.py:87,103-108
         return summary, rec, s
 
