@@ -130,6 +130,8 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
+// (hipcc keeps the loop-carried decision counter in VGPRs, so this mix runs as ~25 VALU instructions; forcing it onto the
+// scalar unit with v_readfirstlane was measured 1.1 % SLOWER -- the dependent s_mul chain lengthens the wave's critical path.)
 __device__ __forceinline__ uint64_t key1(uint64_t seed, uint64_t d) { return mix64(seed + GAMMA * (d + 1)); }
 __device__ __forceinline__ int below(uint32_t r, int n) { return (int)(((uint64_t)r * (uint64_t)(uint32_t)n) >> 32); }
 
