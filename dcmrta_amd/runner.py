@@ -24,12 +24,13 @@ METRIC_KEYS = ("success_rate", "makespan", "time_cost", "waiting_time", "travel_
 
 
 class BatchedRunner:
-    def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=1024):
+    def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=1024, gamma=1.0):
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
         self.base_seed = int(base_seed)
         self.max_steps = int(max_steps)
+        self.gamma = float(gamma)            # GAMMA, parameters.py:6 (1 in the reference)
         if net_factory is None:
             from .policy import AttentionNet
             net_factory = lambda: AttentionNet(6, 5, 128)  # AGENT_INPUT_DIM, TASK_INPUT_DIM, EMBEDDING_DIM (parameters.py:29-31)
@@ -109,7 +110,12 @@ class BatchedRunner:
         last = torch.cumsum(counts, 0) - 1
         rew = torch.zeros((agents.shape[0], 1), dtype=torch.float32, device=agents.device)
         rew[last[counts > 0], 0] = reward[counts > 0].to(torch.float32)          # slot 4: 0 except the last decision (:81,:91)
-        adv = advantage.to(torch.float32)[env_of].unsqueeze(1)                   # slot 6 (:92-101, GAMMA = 1)
+        # slot 6: discount(x, GAMMA) of a vector that is 0 except for the episode advantage at its last decision
+        # (worker.py:14-15,92-101) = GAMMA^(steps to the end) * advantage; GAMMA = 1 gives the advantage everywhere
+        adv = advantage.to(torch.float32)[env_of].unsqueeze(1)
+        if self.gamma != 1.0:
+            to_end = (last[env_of] - torch.arange(agents.shape[0], device=agents.device)).to(torch.float32)
+            adv = adv * torch.pow(torch.tensor(self.gamma, device=agents.device), to_end).unsqueeze(1)
         slots = [agents, tasks, action, mask, rew, agent_id, adv, [], []]
         if as_lists:
             slots = [list(x.unbind(0)) if isinstance(x, torch.Tensor) else x for x in slots]

@@ -61,3 +61,23 @@ def test_testing_greedy_is_deterministic(gpu_device):
     b = r.testing(8, 12, seeds=range(6))
     assert a.shape == (6,) and np.array_equal(a, b) and (a < 0).all()
     assert isinstance(r.testing(8, 12, seed=3), float) and r.testing(8, 12, seed=3) == a[3]
+
+
+def test_discounted_advantage(gpu_device):
+    """discount(x, gamma) of worker.py:14-15 for gamma != 1: reverse discounted cumsum of [0,...,0,adv]."""
+    import scipy.signal as signal
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import BatchedRunner
+    torch.manual_seed(2)
+    r = BatchedRunner(n_envs=3, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32), gamma=0.9)
+    w = r.get_weights()
+    res, _, _ = r.job(w, w, 0, 6, 9)
+    adv, rew = res[6][:, 0].cpu().numpy(), res[4][:, 0].cpu().numpy()
+    ends = np.flatnonzero(rew != 0)
+    lo = 0
+    for b, hi in enumerate(ends):
+        x = np.zeros(hi - lo + 1, np.float32)
+        x[-1] = adv[hi]
+        ref = signal.lfilter([1], [1, -0.9], x[::-1], axis=0)[::-1]
+        np.testing.assert_allclose(adv[lo:hi + 1], ref, rtol=1e-5)
+        lo = hi + 1
