@@ -115,8 +115,8 @@ class OracleEnv:
         lib().orc_set_params(self._h, float(max_waiting_time), float(max_time))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:   # (module globals may already be gone at interpreter exit)
+            _LIB.orc_destroy(self._h)
             self._h = None
 
     def load(self, depot, task_xy, req, dur):

@@ -1,0 +1,18 @@
+"""-m gpu: randomised parity sweep (a short run of tools/sweep.py): random shapes, waiting limits and durations; the persistent
+kernel, the opt-in register-resident kernel and the lockstep API against the oracle, every terminal quantity bit-exact."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_shape_sweep(gpu_device):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "60", "16"], capture_output=True, text=True,
+                         timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("sweep:")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " 0 mismatches" in line[0] and "MISMATCH" not in out.stdout, out.stdout[-3000:]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: many (A, T, seed) shapes, persistent rollout kernel (default and opt-in fast
+kernel) and lockstep API against the oracle.  Developer tool; prints the number of envs checked and any mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+import oracle  # noqa: E402
+from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
+from dcmrta_amd.choice import env_seeds  # noqa: E402
+from dcmrta_amd.instances import generate_batch  # noqa: E402
+
+n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+rng = np.random.default_rng(2026)
+bad, checked, t0 = 0, 0, time.time()
+for it in range(n_shapes):
+    A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
+    T = int(rng.choice([1, 2, 7, 20, 37, 50, 63, 64, 65, 100, 128, 129, 200, 300]))
+    mwt = float(rng.choice([10.0, 10.0, 3.0, 25.0]))
+    base = int(rng.integers(0, 1 << 30))
+    inst = generate_batch(B, A, T, base_seed=base)
+    if it % 3 == 0:   # non-constant durations like the shipped test set (U(0,5))
+        inst["dur"] = rng.random((B, T)) * 5.0
+    seeds = env_seeds(base ^ 0x5A5A, 0, B)
+    refs = []
+    for b in range(B):
+        o = oracle.OracleEnv(A, T, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        refs.append(o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False))
+    for mode in ("rollout", "fast", "lockstep"):
+        if mode == "fast":
+            if A > 64 or T > 64:
+                continue
+            os.environ["DCM_FAST_ROLLOUT"] = "1"
+        else:
+            os.environ.pop("DCM_FAST_ROLLOUT", None)
+        env = BatchedTaskEnv(B, A, T, max_waiting_time=mwt).load_instances(**inst)
+        if mode == "lockstep":
+            if it % 4:
+                continue
+            obs = env.reset(seeds)
+            cnt = np.zeros(B, np.int64)
+            while bool(obs.active.any()):
+                act_host = obs.active.cpu().numpy()
+                mk = obs.mask.cpu().numpy().astype(np.uint8)
+                a = np.array([H.host_random_action(mk[b], int(seeds[b]), int(cnt[b])) if act_host[b] else 0 for b in range(B)], np.int32)
+                cnt += act_host
+                obs = env.step(a)
+            steps = cnt
+        else:
+            env.reset(seeds, observe=False)
+            steps = env.rollout_random(1).cpu().numpy()
+        fin = H.gpu_final(env)
+        for b in range(B):
+            try:
+                assert steps[b] == refs[b]["n_steps"], ("steps", steps[b], refs[b]["n_steps"])
+                H.assert_final_matches(fin[b], refs[b], f"{mode} {A}A{T}T mwt={mwt} base={base} env{b}")
+            except AssertionError as ex:
+                bad += 1
+                print("MISMATCH", mode, A, T, mwt, base, b, str(ex)[:200], flush=True)
+            checked += 1
+        env.close()
+print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {time.time() - t0:.0f} s")
