@@ -31,7 +31,8 @@ struct RLay {
     __device__ uint32_t ainfo() const { return 52 * A; }
     __device__ uint32_t phead() const { return 56 * A; }
     __device__ uint32_t plen() const { return 60 * A; }
-    __device__ uint32_t tb() const { return 64 * A; }
+    __device__ uint32_t amax() const { return 64 * A; }                    // f64[A] max(arrival_time list), :286
+    __device__ uint32_t tb() const { return 72 * A; }
     __device__ uint32_t ts() const { return tb(); }
     __device__ uint32_t tf() const { return tb() + 8 * T; }
     __device__ uint32_t tx() const { return tb() + 16 * T; }
@@ -45,7 +46,7 @@ struct RLay {
     __device__ uint32_t ablog() const { return align16(mid() + MR * T); }  // u16[A][AB_CAP] abandonment log
 };
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16(align16((uint32_t)(64 * A + 48 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
+    return align16(align16((uint32_t)(72 * A + 48 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
 }
 
 struct RP {
@@ -72,6 +73,7 @@ struct Rep {
     __device__ double* nd() const { return (double*)(b + L.nd()); }
     __device__ double* tdist() const { return (double*)(b + L.tdist()); }
     __device__ double* aw() const { return (double*)(b + L.aw()); }
+    __device__ double* amax() const { return (double*)(b + L.amax()); }
     __device__ int32_t* cur() const { return (int32_t*)(b + L.cur()); }
     __device__ uint32_t* ainfo() const { return (uint32_t*)(b + L.ainfo()); }
     __device__ int32_t* phead() const { return (int32_t*)(b + L.phead()); }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
             R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0; R.tw()[t] = 0.0;
         }
         for (int a = lane; a < A; a += WAVE) {
-            R.ax()[a] = depot_x; R.ay()[a] = depot_y; R.arr()[a] = 0.0; R.nd()[a] = 0.0; R.tdist()[a] = 0.0;
+            R.ax()[a] = depot_x; R.ay()[a] = depot_y; R.arr()[a] = 0.0; R.amax()[a] = 0.0; R.nd()[a] = 0.0; R.tdist()[a] = 0.0;
             R.aw()[a] = 0.0; R.cur()[a] = -2; R.ainfo()[a] = 0; R.phead()[a] = 0;
             R.plen()[a] = route_len[(size_t)e * A + a];                      // pre_set_route :595-599 (-1 = None)
         }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         double lmin = __builtin_nan(""), lmax = 0.0;
         for (int a = lane; a < A; a += WAVE) {
             lmin = nanmin2(lmin, R.nd()[a]);
-            const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
+            const double av = R.amax()[a];                                   // max(x) if x else 0 over the whole list
             lmax = av > lmax ? av : lmax;
         }
         const double tmin = wave_nanmin(lmin);
@@ -295,6 +297,9 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
                     const double arrival = now + d / 0.2;                    // :315,:318
                     R.tdist()[a] += d;                                       // :317
                     R.arr()[a] = arrival;
+                    // a member released by its task finishing before it arrived re-decides early, so the list is
+                    // not monotone in replays with surplus visitors; :286 takes the max over the whole list
+                    if (R.cur()[a] == -2 || arrival > R.amax()[a]) R.amax()[a] = arrival;
                     R.ax()[a] = tx_; R.ay()[a] = ty_;                        // :320
                     R.cur()[a] = action - 1;                                 // :314
                     uint32_t ai = R.ainfo()[a] & ~A_MEMBER;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         bool allret = true;
         for (int a = lane; a < A; a += WAVE) {
             l2 = nanmin2(l2, R.nd()[a]);
-            const double av = (R.cur()[a] != -2) ? R.arr()[a] : 0.0;
+            const double av = R.amax()[a];
             m2 = av > m2 ? av : m2;
             allret = allret && (R.ainfo()[a] & A_RETURNED);
         }

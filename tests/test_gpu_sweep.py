@@ -16,3 +16,12 @@ def test_random_shape_sweep(gpu_device):
     line = [l for l in out.stdout.splitlines() if l.startswith("sweep:")]
     assert line, out.stdout[-2000:] + out.stderr[-2000:]
     assert " 0 mismatches" in line[0] and "MISMATCH" not in out.stdout, out.stdout[-3000:]
+
+
+def test_random_replay_sweep(gpu_device):
+    """tools/sweep_replay.py: random routes (None routes, too few / surplus visitors, shuffled order, reactive or not)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_replay.py"), "60"], capture_output=True, text=True,
+                         timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("replay sweep:")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " 0 mismatches" in line[0] and "MISMATCH" not in out.stdout, out.stdout[-3000:]
