@@ -38,6 +38,7 @@ SIGNATURES = {
     "dcm_create": (C.c_int, [C.POINTER(DcmParams), C.POINTER(_vp)]),
     "dcm_destroy": (C.c_int, [_vp]),
     "dcm_load_instances": (C.c_int, [_vp] * 6),
+    "dcm_load_instances_ragged": (C.c_int, [_vp] * 8),   # env, depot, task_xy, req, dur, n_agents (host), n_tasks (host), stream
     "dcm_reset": (C.c_int, [_vp] * 3),
     "dcm_observe": (C.c_int, [_vp] * 8),
     "dcm_step": (C.c_int, [_vp] * 11),

@@ -90,11 +90,25 @@ class BatchedTaskEnv:
         return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
 
     # ------------------------------------------------------------------ instances / reset
-    def load_instances(self, depot, task_xy, req, dur):
-        """depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] int in 1..5, dur[B,T] f64 (numpy or torch)."""
+    def load_instances(self, depot, task_xy, req, dur, n_agents=None, n_tasks=None):
+        """depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] int in 1..5, dur[B,T] f64 (numpy or torch).
+
+        n_agents[B] / n_tasks[B] (host ints, 1..A / 1..T) make the batch ragged: env e is an (n_agents[e], n_tasks[e])
+        env (TaskEnv with tuple ranges, env/task_env.py:58-65), rows beyond its sizes in the arrays are ignored and its
+        observation rows beyond them are padding (-1 features, mask True: attention.py:10-18, worker.py:253-261)."""
         B, T = self.B, self.T
-        req_np = req.cpu().numpy() if isinstance(req, torch.Tensor) else np.asarray(req)
-        if req_np.shape != (B, T) or req_np.min() < 1 or req_np.max() > _lib.MAX_MEMBERS:
+        if (n_agents is None) != (n_tasks is None):
+            raise DcmError("give both n_agents and n_tasks, or neither")
+        req_np = (req.cpu().numpy() if isinstance(req, torch.Tensor) else np.asarray(req)).copy()
+        if req_np.shape != (B, T):
+            raise DcmError(f"req must be int[{B},{T}]")
+        if n_tasks is not None:
+            nt = np.ascontiguousarray(n_tasks, dtype=np.int32)
+            na = np.ascontiguousarray(n_agents, dtype=np.int32)
+            if nt.shape != (B,) or na.shape != (B,):
+                raise DcmError(f"n_agents / n_tasks must be int[{B}]")
+            req_np[np.arange(T)[None, :] >= nt[:, None]] = 1      # ignored rows: anything valid
+        if req_np.min() < 1 or req_np.max() > _lib.MAX_MEMBERS:
             raise DcmError(f"req must be int[{B},{T}] with values in 1..{_lib.MAX_MEMBERS}")
         d = self._dev(depot, torch.float64)
         xy = self._dev(task_xy, torch.float64)
@@ -103,7 +117,14 @@ class BatchedTaskEnv:
         if d.shape != (B, 2) or xy.shape != (B, T, 2) or du.shape != (B, T):
             raise DcmError("instance arrays have the wrong shape")
         with torch.cuda.device(self.device):
-            check(self._lib.dcm_load_instances(self._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du), self._stream()))
+            if n_tasks is None:
+                check(self._lib.dcm_load_instances(self._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du), self._stream()))
+                self.n_agents = self.n_tasks = None
+            else:
+                check(self._lib.dcm_load_instances_ragged(self._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du),
+                                                          na.ctypes.data_as(C.c_void_p), nt.ctypes.data_as(C.c_void_p),
+                                                          self._stream()))
+                self.n_agents, self.n_tasks = na.copy(), nt.copy()
         self._instances = (d, xy, rq, du)  # keep alive until the kernel ran
         return self
 

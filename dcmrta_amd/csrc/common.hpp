@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/dcmrta_env.h"
 
@@ -266,6 +267,8 @@ struct dcm_env {
     double* summary = nullptr;       // [B][8]
     uint16_t* ablog = nullptr;       // [B][A][AB_CAP] abandonment log (side table of the state)
     bool loaded = false, reset_done = false;
+    int32_t* sizes = nullptr;        // [B][2] (A_e, T_e) of a ragged batch (dcm_load_instances_ragged), else nullptr
+    std::vector<int32_t> sizes_host;
     // route replay (dcmrta_replay.hip)
     int32_t* routes = nullptr;       // [B][A][route_cap] actions
     int32_t* route_len = nullptr;    // [B][A], -1 = pre_set_route is None

@@ -85,8 +85,9 @@ struct Sim {
     __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(base + L().amask()); }
     // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
     __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + L().aux()); }
-    __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int lane) const {
-        if (lane == 0) *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * A() * AB_CAP;
+    // (pitch_A = agents per env of the side table = the batch maximum; equals A() unless the batch is ragged)
+    __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int pitch_A, int lane) const {
+        if (lane == 0) *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * pitch_A * AB_CAP;
     }
 
     struct AMask { uint64_t w[NAW]; };
@@ -591,7 +592,7 @@ struct Sim {
     __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
-                                                      const RouteLog* log = nullptr, int env_index = 0,
+                                                      const RouteLog* log = nullptr, int log_row = 0,
                                                       bool no_grouping = false) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
@@ -659,7 +660,7 @@ struct Sim {
                 ai |= (action == 0) ? A_INDEPOT : A_MEMBER;                   // :321-322 listed in the target's members
                 ainfo()[a] = ai;
                 if (log && log->len) {                                        // route.append / arrival_time += (:314,:318)
-                    const size_t o = (size_t)env_index * A_ + a;
+                    const size_t o = (size_t)log_row + a;                     // log_row = env index x agents per env
                     const int c = log->len[o];
                     if (c < log->cap) { log->task[o * log->cap + c] = (int16_t)(action - 1); log->arrival[o * log->cap + c] = arrv[i]; }
                     log->len[o] = c + 1;
@@ -717,17 +718,40 @@ struct Sim {
         if (tk) for (int i = lane; i < 5 * (T() + 1); i += WAVE) tk[i] = 0.f;
         if (mask) for (int i = lane; i <= T(); i += WAVE) mask[i] = (i == 0) ? 0 : 1;
     }
+    // Ragged batch: rows beyond this env's own A / T+1 are padding in the convention the policy already understands --
+    // every feature -1 (attention.py:10-18 get_attn_pad_mask, worker.py:253-261 zero_padding) and mask True (true_padding).
+    __device__ __forceinline__ void write_pad_obs(int lane, int pitch_A, int pitch_T, float* ag, float* tk, uint8_t* mask) const {
+        if (ag) for (int i = 6 * A() + lane; i < 6 * pitch_A; i += WAVE) ag[i] = -1.f;
+        if (tk) for (int i = 5 * (T() + 1) + lane; i < 5 * (pitch_T + 1); i += WAVE) tk[i] = -1.f;
+        if (mask) for (int i = T() + 1 + lane; i <= pitch_T; i += WAVE) mask[i] = 1;
+    }
 };
+
+// Per-env dims.  A uniform batch (sizes == nullptr) uses the kernel's (A,T); a ragged batch (dcm_load_instances_ragged)
+// keeps every record at the pitch of the batch maximum but lays it out for the env's own (A_e,T_e), so the simulator
+// code is unchanged: only the runtime-shape instantiation <0,0> ever sees a ragged batch.
+template <int CA, int CT>
+__device__ __forceinline__ void env_dims(const int32_t* sizes, int e, int A, int T, int& eA, int& eT) {
+    eA = A; eT = T;
+    if constexpr (CA == 0) {
+        if (sizes) { eA = uni(sizes[2 * e]); eT = uni(sizes[2 * e + 1]); }
+    }
+}
+template <int CA, int CT>
+__device__ __forceinline__ Lay pitch_lay(int A, int T) { return Lay{CA ? CA : A, CT ? CT : T}; }
 
 // ---------------------------------------------------------------------------------- kernels
 __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned char* state, const double* depot,
-                                                        const double* task_xy, const int32_t* req, const double* dur) {
+                                                        const double* task_xy, const int32_t* req, const double* dur,
+                                                        const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    const Lay L{A, T};
-    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    int eA, eT;
+    env_dims<0, 0>(sizes, e, A, T, eA, eT);
+    const Lay L{eA, eT};                                       // input arrays and records are pitched by the batch (A,T)
+    unsigned char* rec = state + (size_t)e * Lay{A, T}.rec_bytes();
     double *tx = (double*)(rec + L.tx()), *ty = (double*)(rec + L.ty()), *td = (double*)(rec + L.tdur());
     uint32_t* ti = (uint32_t*)(rec + L.tinfo());
-    for (int t = lane; t < T; t += WAVE) {
+    for (int t = lane; t < eT; t += WAVE) {
         tx[t] = task_xy[((size_t)e * T + t) * 2];
         ty[t] = task_xy[((size_t)e * T + t) * 2 + 1];
         td[t] = dur[(size_t)e * T + t];
@@ -742,14 +766,16 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned 
 
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned char* state, const uint64_t* seeds,
-                                               double* summary, uint16_t* ablog, uint32_t mode) {
+                                               double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<CA, CT> S{A, T, smem};
-    const Lay L = S.L();
-    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    int eA, eT;
+    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT> S{eA, eT, smem};
+    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
+    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    S.set_ablog(ablog, e, lane);
+    S.set_ablog(ablog, e, LP.A, lane);
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
@@ -766,17 +792,19 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
-                                                 const int32_t* leader_in) {
+                                                 const int32_t* leader_in, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<CA, CT> S{A, T, smem};
-    const Lay L = S.L();
-    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    int eA, eT;
+    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT> S{eA, eT, smem};
+    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
+    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
-    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
-    uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
+    float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
+    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
+    uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
     int leader = -1;
     const uint32_t flags0 = h.flags;
     if (!(h.flags & DCM_FLAG_DONE)) {
@@ -785,6 +813,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* s
     }
     if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
     else S.write_inactive_obs(lane, ag, tk, mk);
+    if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
     if (lane == 0) {
         if (leader_out) leader_out[e] = leader;
         if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
@@ -797,14 +826,16 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
-                                              uint16_t* ablog, uint32_t mode) {
+                                              uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<CA, CT> S{A, T, smem};
+    int eA, eT;
+    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT> S{eA, eT, smem};
     using AMask = typename Sim<CA, CT>::AMask;
-    const Lay L = S.L();
-    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
+    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, lane);
+    S.set_ablog(ablog, e, LP.A, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -817,19 +848,20 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e, (mode & DCM_PARAM_NO_GROUPING) != 0);
+                                &log, e * LP.A, (mode & DCM_PARAM_NO_GROUPING) != 0);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
     if (want_obs) {
         WSYNC();
-        float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
-        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
-        uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
+        float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
+        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
+        uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
         int leader = -1;
         if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm); }
         if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
         else S.write_inactive_obs(lane, ag, tk, mk);
+        if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
         if (lane == 0) {
             if (leader_out) leader_out[e] = leader;
             if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
@@ -847,19 +879,23 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
-                                                        int64_t* steps_out, double* summary, uint16_t* ablog) {
+                                                        int64_t* steps_out, double* summary, uint16_t* ablog,
+                                                        const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<CA, CT> S{A, T, smem};
+    int eA, eT;
+    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT> S{eA, eT, smem};
     using AMask = typename Sim<CA, CT>::AMask;
-    const Lay L = S.L();
-    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
+    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, lane);
+    S.set_ablog(ablog, e, LP.A, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;
-    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (L.T + 1) : nullptr;
-    uint8_t* mk = mask_out ? mask_out + (size_t)e * (L.T + 1) : nullptr;
+    float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
+    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
+    uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
+    if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
     double* row = summary + (size_t)e * 8;
     int64_t steps = 0;
     PH_DECL;
@@ -907,53 +943,60 @@ __global__ __launch_bounds__(WAVE) void k_env_status(int A, int T, const unsigne
 __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
-                                                   int32_t* n_abandoned, uint16_t* ablog) {
+                                                   int32_t* n_abandoned, uint16_t* ablog, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<0, 0> S{A, T, smem};
+    int eA, eT;
+    env_dims<0, 0>(sizes, e, A, T, eA, eT);
+    Sim<0, 0> S{eA, eT, smem};
     const Lay L = S.L();
-    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, lane);
+    copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, A, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
-    for (int t = lane; t < T; t += WAVE) {
+    for (int t = lane; t < T; t += WAVE) {                                  // rows t >= T_e of a ragged batch read as 0
         const size_t o = (size_t)e * T + t;
-        const uint32_t info = S.tinfo()[t];
+        const bool in = t < eT;
+        const uint32_t info = in ? S.tinfo()[t] : 0u;
         if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
         if (feasible) feasible[o] = (info & T_FEAS) ? 1 : 0;
-        if (time_start) time_start[o] = S.ts()[t];
-        if (time_finish) time_finish[o] = S.tf()[t];
-        if (sum_wait) sum_wait[o] = S.tw()[t];
+        if (time_start) time_start[o] = in ? S.ts()[t] : 0.0;
+        if (time_finish) time_finish[o] = in ? S.tf()[t] : 0.0;
+        if (sum_wait) sum_wait[o] = in ? S.tw()[t] : 0.0;
         if (status) status[o] = (int)(int8_t)((info >> 8) & 0xFF);
         if (n_members) n_members[o] = (info >> 16) & 0xFF;
-        if (n_abandoned) n_abandoned[o] = (int32_t)S.tnab()[t];
+        if (n_abandoned) n_abandoned[o] = in ? (int32_t)S.tnab()[t] : 0;
     }
 }
 
 __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
-                                                    int32_t* current, int32_t* pending, uint16_t* ablog) {
+                                                    int32_t* current, int32_t* pending, uint16_t* ablog,
+                                                    const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    Sim<0, 0> S{A, T, smem};
+    int eA, eT;
+    env_dims<0, 0>(sizes, e, A, T, eA, eT);
+    Sim<0, 0> S{eA, eT, smem};
     const Lay L = S.L();
-    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, lane);
+    copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
+    S.set_ablog(ablog, e, A, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
-    for (int a = lane; a < A; a += WAVE) {
+    for (int a = lane; a < A; a += WAVE) {                                  // rows a >= A_e of a ragged batch: 0 / NaN timer
         const size_t o = (size_t)e * A + a;
-        const uint32_t ai = S.ainfo()[a];
-        if (sum_wait) sum_wait[o] = S.aw()[a];
-        if (travel_dist) travel_dist[o] = S.tdist()[a];
-        if (next_decision) next_decision[o] = S.nd()[a];
-        if (arrival) arrival[o] = S.arr()[a];
-        if (x) x[o] = S.ax()[a];
-        if (y) y[o] = S.ay()[a];
+        const bool in = a < eA;
+        const uint32_t ai = in ? S.ainfo()[a] : 0u;
+        if (sum_wait) sum_wait[o] = in ? S.aw()[a] : 0.0;
+        if (travel_dist) travel_dist[o] = in ? S.tdist()[a] : 0.0;
+        if (next_decision) next_decision[o] = in ? S.nd()[a] : __builtin_nan("");
+        if (arrival) arrival[o] = in ? S.arr()[a] : 0.0;
+        if (x) x[o] = in ? S.ax()[a] : 0.0;
+        if (y) y[o] = in ? S.ay()[a] : 0.0;
         if (returned) returned[o] = (ai & A_RETURNED) ? 1 : 0;
         if (assigned) assigned[o] = (ai & A_ASSIGNED) ? 1 : 0;
-        if (current) current[o] = S.cur()[a];
+        if (current) current[o] = in ? S.cur()[a] : -2;
         if (pending) pending[o] = (int32_t)((ai >> 8) & 0xFFu);
     }
 }
@@ -975,6 +1018,13 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
         else if ((A) == 50 && (T) == 200) { CALL(50, 200); }             \
         else if ((A) == 100 && (T) == 500) { CALL(100, 500); }           \
         else { CALL(0, 0); }                                             \
+    } while (0)
+
+// a ragged batch (per-env sizes) always takes the runtime-shape instantiation
+#define DISPATCH_ENV(env, CALL)                                          \
+    do {                                                                 \
+        if ((env)->sizes) { CALL(0, 0); }                                \
+        else DISPATCH_SHAPE((env)->L.A, (env)->L.T, CALL);               \
     } while (0)
 
 }  // namespace
@@ -1024,6 +1074,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     (void)hipFuncSetAttribute((const void*)k_step<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
     (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     DISPATCH_SHAPE(params->n_agents, params->n_tasks, SET_ATTR);
+    SET_ATTR(0, 0);
 #undef SET_ATTR
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<20, 50>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1041,6 +1092,7 @@ int dcm_destroy(dcm_env* env) {
     if (env->ablog) (void)hipFree(env->ablog);
     if (env->routes) (void)hipFree(env->routes);
     if (env->route_len) (void)hipFree(env->route_len);
+    if (env->sizes) (void)hipFree(env->sizes);
     delete env;
     return DCM_OK;
 }
@@ -1050,8 +1102,33 @@ int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy,
                        void* stream) {
     CHECK_ENV(env);
     if (!depot || !task_xy || !req || !dur) return fail(DCM_ERR_INVALID, "dcm_load_instances: null array");
+    if (env->sizes) { HIP_TRY(hipFree(env->sizes)); env->sizes = nullptr; }   // back to a uniform batch (hipFree synchronises)
     hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, env->L.A, env->L.T, env->state, depot, task_xy,
-                       req, dur);
+                       req, dur, (const int32_t*)nullptr);
+    LAUNCH_OK();
+    env->loaded = true;
+    env->reset_done = false;
+    return DCM_OK;
+}
+
+int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* task_xy, const int32_t* req,
+                              const double* dur, const int32_t* n_agents_host, const int32_t* n_tasks_host, void* stream) {
+    CHECK_ENV(env);
+    if (!depot || !task_xy || !req || !dur || !n_agents_host || !n_tasks_host)
+        return fail(DCM_ERR_INVALID, "dcm_load_instances_ragged: null array");
+    const int B = env->p.n_envs;
+    env->sizes_host.resize((size_t)2 * B);
+    for (int e = 0; e < B; e++) {
+        const int a = n_agents_host[e], t = n_tasks_host[e];
+        if (a < 1 || a > env->L.A || t < 1 || t > env->L.T)
+            return fail(DCM_ERR_INVALID, "dcm_load_instances_ragged: need 1 <= n_agents[e] <= A and 1 <= n_tasks[e] <= T");
+        env->sizes_host[2 * (size_t)e] = a; env->sizes_host[2 * (size_t)e + 1] = t;
+    }
+    if (!env->sizes) HIP_TRY(hipMalloc((void**)&env->sizes, (size_t)2 * B * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(env->sizes, env->sizes_host.data(), (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, env->L.A, env->L.T, env->state, depot, task_xy,
+                       req, dur, (const int32_t*)env->sizes);
     LAUNCH_OK();
     env->loaded = true;
     env->reset_done = false;
@@ -1064,8 +1141,8 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT)                                                                                                  \
     hipLaunchKernelGGL((k_reset<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
-                       env->state, seeds, env->summary, env->ablog, env->p.flags)
-    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+                       env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes)
+    DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
     if (env->log.len)
@@ -1089,8 +1166,9 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
 #define CALL(CA, CT)                                                                                                    \
     hipLaunchKernelGGL((k_observe<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,     \
-                       env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in)
-    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+                       env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
+                       (const int32_t*)env->sizes)
+    DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
     return DCM_OK;
@@ -1107,8 +1185,8 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
 #define CALL(CA, CT)                                                                                                 \
     hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary, env->log, env->ablog, env->p.flags)
-    DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+                       active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes)
+    DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
     return DCM_OK;
@@ -1121,16 +1199,17 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, float* agents_out, float*
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
 #define CALL(CA, CT)                                                                                                  \
     hipLaunchKernelGGL((k_rollout_random<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, \
-                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog)
+                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
+                       (const int32_t*)env->sizes)
 #define CALL_FAST(CA, CT)                                                                                             \
     hipLaunchKernelGGL((k_rollout_fast<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,  \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog)
-    if (env->L.A <= 64 && env->L.T <= 64 && getenv("DCM_FAST_ROLLOUT")) {
+    if (env->L.A <= 64 && env->L.T <= 64 && !env->sizes && getenv("DCM_FAST_ROLLOUT")) {
         // opt-in register-resident kernel: lane t owns task t, lane a owns agent a (fast_rollout.hpp); parity-green but
         // measured 3 % slower than the LDS-resident kernel at 20A/50T (0.695 vs 0.675 ms/launch), so not the default
         if (env->L.A == 20 && env->L.T == 50) { CALL_FAST(20, 50); } else { CALL_FAST(0, 0); }
     } else {
-        DISPATCH_SHAPE(env->L.A, env->L.T, CALL);
+        DISPATCH_ENV(env, CALL);
     }
 #undef CALL_FAST
 #undef CALL
@@ -1160,7 +1239,7 @@ int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* ti
     CHECK_ENV(env);
     hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned,
-                       env->ablog);
+                       env->ablog, (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1171,7 +1250,7 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
     CHECK_ENV(env);
     hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
-                       pending_group, env->ablog);
+                       pending_group, env->ablog, (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
 }

@@ -468,6 +468,7 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     CHECK_ENV(env);
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_instances first");
     if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
+    if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");
     const uint32_t lds = replay_lds_bytes(env->L.A, env->L.T, env->member_cap);
     (void)hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     RP P{100.0, 200.0, reactive ? 1 : 0};  // env/task_env.py:564-565

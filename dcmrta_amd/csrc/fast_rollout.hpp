@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, KP P, un
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, lane);
+    S.set_ablog(ablog, e, S.A(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;

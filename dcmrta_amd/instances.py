@@ -52,6 +52,27 @@ def generate_batch(B, A, T, base_seed=0, first=0, max_coalition_size=5, max_dura
     return dict(depot=depot, task_xy=task_xy, req=req, dur=dur)
 
 
+def generate_batch_ranges(seeds, agents_range, tasks_range, max_coalition_size=5, max_duration=5.0):
+    """Ragged batch: instance b = TaskEnv(agents_range, tasks_range, seed=seeds[b]) (runner.py:45-49 with the tuple
+    ranges of parameters.py:15-16).  Arrays are padded to the range maxima (task rows beyond n_tasks[b]: xy 0, req 1,
+    dur 0 -- ignored by dcm_load_instances_ragged); returns the load_instances keyword dict incl. n_agents / n_tasks."""
+    seeds = list(seeds)
+    B = len(seeds)
+    A = int(agents_range[1]) if isinstance(agents_range, tuple) else int(agents_range)
+    T = int(tasks_range[1]) if isinstance(tasks_range, tuple) else int(tasks_range)
+    out = dict(depot=np.zeros((B, 2)), task_xy=np.zeros((B, T, 2)), req=np.ones((B, T), np.int32), dur=np.zeros((B, T)),
+               n_agents=np.zeros(B, np.int32), n_tasks=np.zeros(B, np.int32))
+    for b, s in enumerate(seeds):
+        a, inst = generate_instance_ranges(agents_range, tasks_range, int(s), max_coalition_size, max_duration)
+        t = inst["req"].shape[0]
+        out["depot"][b] = inst["depot"]
+        out["task_xy"][b, :t] = inst["task_xy"]
+        out["req"][b, :t] = inst["req"]
+        out["dur"][b, :t] = inst["dur"]
+        out["n_agents"][b], out["n_tasks"][b] = a, t
+    return out
+
+
 def load_instances_npz(path):
     """Fixture format of tests/golden/instances_20A50T.npz (depot[N,2], task_xy[N,T,2], req[N,T], dur[N,T], A)."""
     z = np.load(path)

@@ -18,7 +18,7 @@ import torch
 
 from .batched_env import BatchedTaskEnv
 from .choice import env_seeds
-from .instances import generate_batch
+from .instances import generate_batch, generate_batch_ranges
 
 METRIC_KEYS = ("success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency")
 
@@ -122,14 +122,26 @@ class BatchedRunner:
         return slots
 
     # ------------------------------------------------------------------ runner.py:58-71
+    @staticmethod
+    def _is_range(x):
+        return isinstance(x, (tuple, list)) and int(x[0]) != int(x[1])
+
     def job(self, global_weights, baseline_weights, episodeNumber, agents_num, tasks_num, as_lists=False):
+        """agents_num / tasks_num: ints as driver.py:114-117 passes them, or (lo, hi) ranges as Worker's defaults
+        (worker.py:26) -- then every env draws its own sizes (env/task_env.py:58-65) and the batch is ragged: the
+        experience rows are padded to (hi_A, hi_T + 1) with -1 rows / True mask (worker.py:253-261)."""
         self.set_weights(global_weights)
         self.set_baseline_weights(baseline_weights)
-        A = int(agents_num[1] if isinstance(agents_num, tuple) else agents_num)
-        T = int(tasks_num[1] if isinstance(tasks_num, tuple) else tasks_num)
+        A = int(agents_num[1] if isinstance(agents_num, (tuple, list)) else agents_num)
+        T = int(tasks_num[1] if isinstance(tasks_num, (tuple, list)) else tasks_num)
         env = self._get_env(A, T)
         first = int(episodeNumber) * self.B
-        inst = generate_batch(self.B, A, T, base_seed=self.base_seed, first=first)   # worker.py:32
+        if self._is_range(agents_num) or self._is_range(tasks_num):
+            inst = generate_batch_ranges(range(self.base_seed + first, self.base_seed + first + self.B),
+                                         tuple(agents_num) if isinstance(agents_num, (tuple, list)) else int(agents_num),
+                                         tuple(tasks_num) if isinstance(tasks_num, (tuple, list)) else int(tasks_num))
+        else:
+            inst = generate_batch(self.B, A, T, base_seed=self.base_seed, first=first)   # worker.py:32
         env.load_instances(**inst)
         seeds = env_seeds(self.base_seed, first, self.B)
         summary, rec, n_steps = self.rollout(self.localNetwork, env, seeds, greedy=False, record=True)   # run_episode
@@ -144,20 +156,25 @@ class BatchedRunner:
         return jobResults, metrics, info
 
     # ------------------------------------------------------------------ runner.py:45-49 (greedy evaluation)
-    def testing(self, agents_range=20, tasks_range=50, seed=None, seeds=None):
-        """Greedy reward(s) of the local network on seeded instances; seed -> float, seeds -> numpy array."""
-        A = int(agents_range[1] if isinstance(agents_range, tuple) else agents_range)
-        T = int(tasks_range[1] if isinstance(tasks_range, tuple) else tasks_range)
+    def testing(self, agents_range=(10, 20), tasks_range=(20, 50), seed=None, seeds=None):
+        """Greedy reward(s) of the local network on seeded instances; seed -> float, seeds -> numpy array.
+
+        Defaults are the reference's AGENTS_RANGE / TASKS_RANGE (parameters.py:15-16, runner.py:45): with (lo, hi)
+        ranges every seed draws its own sizes (env/task_env.py:58-65), so the seeds of one call form a ragged batch."""
+        A = int(agents_range[1] if isinstance(agents_range, (tuple, list)) else agents_range)
+        T = int(tasks_range[1] if isinstance(tasks_range, (tuple, list)) else tasks_range)
+        ar = tuple(agents_range) if isinstance(agents_range, (tuple, list)) else int(agents_range)
+        tr = tuple(tasks_range) if isinstance(tasks_range, (tuple, list)) else int(tasks_range)
         ss = [seed if seed is not None else 0] if seeds is None else list(seeds)
         out = []
         env = self._get_env(A, T)
         for i in range(0, len(ss), self.B):
             chunk = ss[i:i + self.B]
             pad = chunk + [chunk[-1]] * (self.B - len(chunk))
-            from .instances import generate_instance
-            insts = [generate_instance(A, T, s) for s in pad]
-            env.load_instances(np.stack([x["depot"] for x in insts]), np.stack([x["task_xy"] for x in insts]),
-                               np.stack([x["req"] for x in insts]), np.stack([x["dur"] for x in insts]))
+            inst = generate_batch_ranges(pad, ar, tr)      # same draw order as TaskEnv(ar, tr, seed=s), sizes first
+            if not (self._is_range(ar) or self._is_range(tr)):
+                inst.pop("n_agents"); inst.pop("n_tasks")  # uniform batch: shape-specialised kernels
+            env.load_instances(**inst)
             cs = np.array([env_seeds(self.base_seed, int(s), 1)[0] for s in pad], dtype=np.uint64)
             summary, _, _ = self.rollout(self.localNetwork, env, cs, greedy=True, record=False)
             out.extend(summary[:len(chunk), 0].cpu().numpy().tolist())

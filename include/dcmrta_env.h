@@ -86,6 +86,19 @@ int dcm_destroy(dcm_env *env);
 int dcm_load_instances(dcm_env *env, const double *depot, const double *task_xy, const int32_t *req,
                        const double *dur, void *stream);
 
+/* Ragged batch: TaskEnv(agents_range=(lo,hi), tasks_range=(lo,hi)) draws its own sizes per env
+ * (env/task_env.py:58-65), which is what Runner.testing(seed) does with the default ranges
+ * (runner.py:45-49, parameters.py:15-16).  Env e has n_agents[e] <= A agents and n_tasks[e] <= T tasks
+ * and behaves exactly like an (n_agents[e], n_tasks[e]) env; the device arrays keep the batch shapes
+ * of dcm_load_instances (rows beyond an env's own sizes are ignored).  Every output keeps the batch
+ * shapes too: observation rows beyond an env's sizes are padding in the policy's convention --
+ * all features -1 (attention.py:10-18, worker.py:253-257) and mask True (worker.py:258-261); getter
+ * rows beyond the sizes read as 0 (next_decision NaN, current -2).  n_agents / n_tasks are HOST
+ * arrays of B int32 (validated here).  dcm_load_instances switches back to a uniform batch.
+ * Route replay (dcm_execute_routes) needs a uniform batch. */
+int dcm_load_instances_ragged(dcm_env *env, const double *depot, const double *task_xy, const int32_t *req,
+                              const double *dur, const int32_t *n_agents, const int32_t *n_tasks, void *stream);
+
 /* reset + clear_decisions (env/task_env.py:116-140) for every env, then advance each env to its
  * first decision point (event t=0, one group of all agents; worker.py:45-51).
  * seeds[B] u64: per-env seed of the choice protocol; the decision counter restarts at 0. */

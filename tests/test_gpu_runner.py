@@ -81,3 +81,41 @@ def test_discounted_advantage(gpu_device):
         ref = signal.lfilter([1], [1, -0.9], x[::-1], axis=0)[::-1]
         np.testing.assert_allclose(adv[lo:hi + 1], ref, rtol=1e-5)
         lo = hi + 1
+
+
+def test_ragged_job_and_testing(gpu_device, oracle_lib):
+    """(lo, hi) ranges: every env of the job draws its own sizes like TaskEnv(agents_range, tasks_range, seed)
+    (env/task_env.py:58-65); the padded experience replays through the oracle at each env's own size."""
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch_ranges
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import BatchedRunner
+    torch.manual_seed(4)
+    B, AR, TR = 8, (4, 9), (6, 15)
+    r = BatchedRunner(n_envs=B, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32), base_seed=21)
+    w = {k: v.clone() for k, v in r.get_weights().items()}
+    res, metrics, _ = r.job(w, w, 1, AR, TR)
+    agents, tasks, action, mask, reward, agent_id = (res[k].cpu().numpy() for k in range(6))
+    assert agents.shape[1:] == (AR[1], 6) and tasks.shape[1:] == (TR[1] + 1, 5) and mask.shape[1] == TR[1] + 1
+    inst = generate_batch_ranges(range(21 + B, 21 + 2 * B), AR, TR)
+    assert len(set(inst["n_agents"].tolist())) > 1 and len(set(inst["n_tasks"].tolist())) > 1
+    seeds = env_seeds(21, B, B)
+    summary = r.last["summary"].cpu().numpy()
+    ends = np.concatenate([[-1], np.flatnonzero(reward[:, 0] != 0)])
+    assert len(ends) == B + 1
+    for b in range(B):
+        a, t = int(inst["n_agents"][b]), int(inst["n_tasks"][b])
+        lo, hi = ends[b] + 1, ends[b + 1] + 1
+        o = oracle_lib.OracleEnv(a, t).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_INJECTED, cap_steps=4096, inj_action=action[lo:hi, 0].astype(np.int32))
+        assert ref["n_steps"] == hi - lo and ref["reward"] == summary[b, 0]
+        assert np.array_equal(ref["leader"], agent_id[lo:hi, 0, 0])
+        assert np.array_equal(ref["agents_obs"], agents[lo:hi, :a]) and np.all(agents[lo:hi, a:] == -1)
+        assert np.array_equal(ref["tasks_obs"], tasks[lo:hi, :t + 1]) and np.all(tasks[lo:hi, t + 1:] == -1)
+        assert np.array_equal(ref["mask"], mask[lo:hi, :t + 1].astype(np.uint8)) and mask[lo:hi, t + 1:].all()
+        assert (action[lo:hi, 0] <= t).all()
+    # testing() with ranges (runner.py:45-49 defaults): ragged greedy evaluation, deterministic, one reward per seed
+    rewards = r.testing(AR, TR, seeds=range(40, 46))
+    assert rewards.shape == (6,) and (rewards < 0).all()
+    assert np.array_equal(rewards, r.testing(AR, TR, seeds=range(40, 46)))
+    assert r.testing(AR, TR, seed=43) == rewards[3]

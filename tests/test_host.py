@@ -122,3 +122,19 @@ def test_instance_generator_with_ranges(golden_dir):
         assert (A, len(inst["req"])) == (r["A"], r["T"])
         assert inst["depot"].tolist() == r["depot"] and inst["task_xy"][0].tolist() == r["task_xy0"]
         assert inst["task_xy"][-1].tolist() == r["task_xy_last"] and inst["req"].tolist() == r["req"]
+
+
+def test_ragged_batch_generator_matches_reference_sizes(golden_dir):
+    """generate_batch_ranges pads the per-seed instances of the reference (instances_ranges.json) to the range maxima."""
+    import json
+    from dcmrta_amd.instances import generate_batch_ranges
+    ref = json.load(open(os.path.join(golden_dir, "instances_ranges.json")))
+    seeds = [int(s) for s in ref]
+    inst = generate_batch_ranges(seeds, (10, 20), (20, 50))
+    assert inst["task_xy"].shape == (len(seeds), 50, 2) and inst["req"].shape == (len(seeds), 50)
+    for b, s in enumerate(seeds):
+        r = ref[str(s)]
+        a, t = int(inst["n_agents"][b]), int(inst["n_tasks"][b])
+        assert (a, t) == (r["A"], r["T"]) and inst["depot"][b].tolist() == r["depot"]
+        assert inst["req"][b, :t].tolist() == r["req"] and inst["task_xy"][b, t - 1].tolist() == r["task_xy_last"]
+        assert (inst["req"][b, t:] == 1).all() and not inst["task_xy"][b, t:].any() and (inst["dur"][b, :t] == 5.0).all()

@@ -31,3 +31,28 @@ def test_policy_contract_shapes():
         lp = net(torch.rand(B, T + 1, 5), torch.rand(B, A, 6), mask)
     assert lp.shape == (B, T + 1) and torch.isfinite(lp).all()
     assert (lp.argmax(1) != 0).all()
+
+
+def test_policy_padding_rows():
+    """A ragged batch pads agents/tasks with -1 rows and True mask (worker.py:253-261); all -1 rows are padding for the
+    attention masks (attention.py:10-18).  Padded tasks are ignored exactly; padded AGENTS are ignored everywhere except
+    globalDecoder1, which the reference calls without a mask (attention.py:295) -- restated as is, so only the
+    task-padded forward is required to equal the unpadded one."""
+    import torch
+    from dcmrta_amd.policy import AttentionNet
+    torch.manual_seed(0)
+    net = AttentionNet(6, 5, 32).eval()
+    A, T, a, t = 9, 15, 5, 8
+    agents, tasks = torch.rand(2, a, 6), torch.rand(2, t + 1, 5)
+    mask = torch.rand(2, t + 1) < 0.3
+    mask[:, 0] = False
+    pa = torch.full((2, A, 6), -1.0); pa[:, :a] = agents
+    pt = torch.full((2, T + 1, 5), -1.0); pt[:, :t + 1] = tasks
+    pm = torch.ones(2, T + 1, dtype=torch.bool); pm[:, :t + 1] = mask
+    with torch.no_grad():
+        ref, tpad, both = net(tasks, agents, mask), net(pt, agents, pm), net(pt, pa, pm)
+    live = ~mask
+    assert torch.allclose(tpad[:, :t + 1][live], ref[live], atol=1e-5)
+    for got in (tpad, both):
+        assert torch.isfinite(got).all() and (got[:, t + 1:].exp() == 0).all()   # padded actions have probability 0
+        assert torch.allclose(got.exp().sum(1), torch.ones(2), atol=1e-5)
