@@ -19,7 +19,9 @@ from dcmrta_amd.instances import generate_batch  # noqa: E402
 
 n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2026)
+TASK_KEYS = ("finished", "feasible", "time_start", "time_finish", "task_wait", "n_members", "n_abandoned")
+AGENT_KEYS = ("travel_dist", "returned", "agent_wait")
 bad, checked, t0 = 0, 0, time.time()
 for it in range(n_shapes):
     A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
@@ -30,20 +32,26 @@ for it in range(n_shapes):
     if it % 3 == 0:   # non-constant durations like the shipped test set (U(0,5))
         inst["dur"] = rng.random((B, T)) * 5.0
     seeds = env_seeds(base ^ 0x5A5A, 0, B)
+    ragged = (it % 5 == 2)   # every env of the batch gets its own (A_e, T_e) <= (A, T): dcm_load_instances_ragged
+    nA = rng.integers(1, A + 1, B).astype(np.int32) if ragged else np.full(B, A, np.int32)
+    nT = rng.integers(1, T + 1, B).astype(np.int32) if ragged else np.full(B, T, np.int32)
+    if ragged:
+        inst["n_agents"], inst["n_tasks"] = nA, nT
     refs = []
     for b in range(B):
-        o = oracle.OracleEnv(A, T, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        a, t = int(nA[b]), int(nT[b])
+        o = oracle.OracleEnv(a, t, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
         refs.append(o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False))
     for mode in ("rollout", "fast", "lockstep"):
         if mode == "fast":
-            if A > 64 or T > 64:
+            if A > 64 or T > 64 or ragged:
                 continue
             os.environ["DCM_FAST_ROLLOUT"] = "1"
         else:
             os.environ.pop("DCM_FAST_ROLLOUT", None)
         env = BatchedTaskEnv(B, A, T, max_waiting_time=mwt).load_instances(**inst)
         if mode == "lockstep":
-            if it % 4:
+            if it % 4 and not (ragged and it % 2):
                 continue
             obs = env.reset(seeds)
             cnt = np.zeros(B, np.int64)
@@ -61,7 +69,12 @@ for it in range(n_shapes):
         for b in range(B):
             try:
                 assert steps[b] == refs[b]["n_steps"], ("steps", steps[b], refs[b]["n_steps"])
-                H.assert_final_matches(fin[b], refs[b], f"{mode} {A}A{T}T mwt={mwt} base={base} env{b}")
+                f = dict(fin[b])
+                for k in TASK_KEYS:
+                    f[k] = f[k][:nT[b]]
+                for k in AGENT_KEYS:
+                    f[k] = f[k][:nA[b]]
+                H.assert_final_matches(f, refs[b], f"{mode} {A}A{T}T mwt={mwt} base={base} env{b} ragged={ragged}")
             except AssertionError as ex:
                 bad += 1
                 print("MISMATCH", mode, A, T, mwt, base, b, str(ex)[:200], flush=True)

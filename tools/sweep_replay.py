@@ -14,7 +14,7 @@ from dcmrta_amd.instances import generate_batch  # noqa: E402
 
 n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = 12
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
 KEYS = ("finished", "time_start", "time_finish", "task_wait", "n_members", "travel_dist", "returned", "agent_wait")
 bad = checked = trunc = terr = 0
 t0 = time.time()
