@@ -223,6 +223,23 @@ __device__ __forceinline__ double dist2(double ax, double ay, double bx, double 
     const double dx = ax - bx, dy = ay - by;
     return sqrt(__builtin_fma(dy, dy, dx * dx));
 }
+// travel_time = distance / velocity with velocity 0.2 (env/task_env.py:99,315).  The IEEE quotient d / 0.2 costs an
+// 11-instruction v_div_scale / v_rcp_f64 / v_div_fmas sequence; Markstein's division by a constant gives the same
+// correctly rounded result in three: 5.0 = RN(1/0.2) (1/0.2 = 5 - 2.8e-16, half an ulp below 5 is 4.4e-16),
+// q = RN(5d) is a faithful quotient (|5d - d/0.2| = 2^-54 relative), r = d - 0.2 q is exact in one fma, and then
+// RN(q + 5 r) = RN(d / 0.2) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, thm. on
+// "correcting a faithful quotient").  Needs no overflow/underflow in q and r: any distance between finite points
+// that is 0 or in [2^-900, 2^1000].  Pinned against the true quotient by tests/test_gpu_parity.py (distance KATs,
+// 2^22 random distances over 600 binades).
+#ifndef DCM_IEEE_DIV
+__device__ __forceinline__ double over_velocity(double d) {
+    const double q = d * 5.0;
+    const double r = __builtin_fma(-q, 0.2, d);
+    return __builtin_fma(r, 5.0, q);
+}
+#else
+__device__ __forceinline__ double over_velocity(double d) { return d / 0.2; }
+#endif
 
 // ---------------------------------------------------------------------------------- record I/O
 __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {

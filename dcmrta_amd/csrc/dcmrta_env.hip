@@ -650,7 +650,7 @@ struct Sim {
             arrv[i] = 0.0;
             if (a < A_ && ((mm.w[i] >> lane) & 1ull)) {
                 const double d = dist2(ax()[a], ay()[a], tx_, ty_);
-                const double travel_time = d / 0.2;                           // :315 velocity 0.2 (:99)
+                const double travel_time = over_velocity(d);                          // :315 velocity 0.2 (:99)
                 tdist()[a] += d;                                              // :317
                 arrv[i] = h.now + travel_time;                                // :318
                 arr()[a] = arrv[i];
@@ -899,6 +899,10 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     double* row = summary + (size_t)e * 8;
     int64_t steps = 0;
     PH_DECL;
+    // key_1 = mix64(seed + GAMMA (d+1)): the argument is carried and advanced by GAMMA per decision (no 64-bit multiply,
+    // and neither seed nor d stay live in the loop: d = d0 + steps afterwards)
+    uint64_t gd = h.seed + GAMMA * (h.d + 1);
+    const uint64_t d0 = h.d;
     for (int ep = 0; ep < episodes; ep++) {
         if (h.flags & DCM_FLAG_DONE) {  // restart from the loaded instance; d keeps running
             if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) break;
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
         }
         while (!(h.flags & DCM_FLAG_DONE)) {
             AMask gm;
-            const uint64_t k1 = key1(h.seed, h.d);
+            const uint64_t k1 = mix64(gd);
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
             PH_MARK(0);
@@ -917,11 +921,15 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
             const int action = S.pick_random_action(lane, k1);
             PH_MARK(2);
             S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS);
+            gd += GAMMA;
             steps++;
         }
     }
     PH_FLUSH(lane);
     if (lane == 0 && steps_out) steps_out[e] = steps;
+#ifndef DCM_KEEP_D
+    h.d = d0 + (uint64_t)steps;   // every decision of this kernel is valid, so apply_and_advance counted exactly `steps`
+#endif
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
@@ -1007,7 +1015,7 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
     if (i >= n) return;
     const double d = dist2(ax[i], ay[i], bx[i], by[i]);
     if (dist_out) dist_out[i] = d;
-    if (time_out) time_out[i] = d / 0.2;
+    if (time_out) time_out[i] = over_velocity(d);
 }
 
 // ---------------------------------------------------------------------------------- host side

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
                 const double tx_ = action ? uni(R.tx()[action - 1]) : depot_x, ty_ = action ? uni(R.ty()[action - 1]) : depot_y;
                 if (lane == 0) {
                     const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
-                    const double arrival = now + d / 0.2;                    // :315,:318
+                    const double arrival = now + over_velocity(d);                  // :315,:318
                     R.tdist()[a] += d;                                       // :317
                     R.arr()[a] = arrival;
                     // a member released by its task finishing before it arrived re-decides early, so the list is

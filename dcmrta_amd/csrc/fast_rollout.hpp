@@ -255,7 +255,7 @@ struct Fast {
         // agent_step (:300-324) for every member lane; the other lanes compute and discard
         const bool is_m = (mm >> lane) & 1ull;
         const double d = dist2(s.ax, s.ay, tx_, ty_);
-        const double arr_new = h.now + d / 0.2;                               // :315,:318
+        const double arr_new = h.now + over_velocity(d);                             // :315,:318
         s.tdist = is_m ? s.tdist + d : s.tdist;                               // :317
         s.arr = is_m ? arr_new : s.arr;
         s.ax = is_m ? tx_ : s.ax; s.ay = is_m ? ty_ : s.ay;                   // :320

@@ -32,6 +32,22 @@ def test_distance_known_answers(gpu_device, golden_dir):
     assert np.array_equal(t, z["dist"] / 0.2)
 
 
+def test_travel_time_division_is_ieee(gpu_device):
+    """travel_time = d / 0.2 (env/task_env.py:315) is computed as Markstein's 3-instruction division by a constant
+    (csrc/common.hpp over_velocity); it must be the correctly rounded IEEE quotient for every distance: 2^22 random
+    mantissas over 600 binades + the unit-square range the instances live in."""
+    from dcmrta_amd.batched_env import device_distance
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    wide = np.ldexp(1.0 + rng.random(n), rng.integers(-300, 300, n))
+    unit = rng.random(n) * 1.5
+    x = np.concatenate([wide, unit, [0.0, 0.2, 1.0, 5.0, 2.0 ** -900, 2.0 ** 1000]])
+    a = np.stack([x, np.zeros_like(x)], 1)
+    d, t = device_distance(a, np.zeros_like(a), gpu_device)
+    assert np.array_equal(d, x)
+    assert np.array_equal(t, x / 0.2)
+
+
 def _groups():
     g = {}
     for p in H.full_traces():
