@@ -33,11 +33,34 @@ from dcmrta_amd.instances import generate_batch  # noqa: E402
 from dcmrta_amd.roofline import HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step  # noqa: E402
 
 
-def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
+def usable_cores():
+    """Host threads this process may really run on: min(cpu_count, affinity mask, cgroup CPU quota).  (The GPU box shows
+    256 hardware threads but a cgroup quota of 16 CPUs: 256 runnable threads get throttled to below the 16-thread rate.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]      # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(inst, seeds, A, target_core_seconds=20.0):
     """The oracle (bit-parity C restatement of the reference) on the host cores: baseline, not target."""
     import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     B = len(seeds)
     # calibrate on a small slice, then size the sample to ~target_core_seconds of CPU work
     t0 = time.perf_counter()
@@ -52,7 +75,8 @@ def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
     dt = time.perf_counter() - t0
     return dict(value=n / dt, unit="steps/s", cores=cores, kind="port",
                 sample=f"{B} envs x {episodes} episodes ({n} decisions) of the same instances/seeds, oracle C port, "
-                       f"{cores} threads, one env per thread")
+                       f"{cores} threads (= usable host CPUs: cpu_count {os.cpu_count()}, cgroup/affinity limit {cores}), "
+                       f"one env per thread")
 
 
 def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
