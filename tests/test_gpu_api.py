@@ -126,25 +126,37 @@ def test_full_size_properties(gpu_device):
         assert int(s1.min()) > 0
 
 
-def test_individual_selection_mode(gpu_device, oracle_lib):
+@pytest.mark.parametrize("A,T,policy", [(8, 14, "first"), (20, 50, "random"), (3, 40, "random"), (33, 9, "random"), (70, 70, "last")])
+def test_individual_selection_mode(gpu_device, oracle_lib, A, T, policy):
     """Worker.run_test_IS (worker.py:159-198): every deciding agent acts alone, in ascending id order, without
-    get_unique_group; greedy "first valid action" policy.  Reference loop restated on the oracle's step-wise surface."""
+    get_unique_group.  Reference loop restated on the oracle's step-wise surface; the action is a deterministic function
+    of the mask (first / last / keyed-random valid action) so both sides take the same decisions."""
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
-    B, A, T = 4, 8, 14
+    B = 4
     inst = generate_batch(B, A, T, base_seed=61)
+
+    def choose(mask_row, b, i):
+        valid = np.flatnonzero(np.asarray(mask_row) == 0)
+        if policy == "first":
+            return int(valid[0])
+        if policy == "last":
+            return int(valid[-1])
+        return int(valid[(1103515245 * (i + 7 * b + 1) + 12345) % len(valid)])
+
     env = BatchedTaskEnv(B, A, T, device=gpu_device, individual_selection=True).load_instances(**inst)
     env.reset(np.arange(B, dtype=np.uint64), observe=False)
     # device: always inject the lowest pending agent as leader, no followers
     steps = np.zeros(B, int)
-    for _ in range(2000):
+    for _ in range(5000):
         pg = env.agents_state()["pending_group"].cpu().numpy()
         flags = env.status()["flags"].cpu().numpy()
         if (flags & 1).all():
             break
         lead = np.array([int(np.flatnonzero(pg[b] > 0)[0]) if not (flags[b] & 1) else -1 for b in range(B)], np.int32)
         obs = env.observe(leader=lead)
-        act = torch.argmax((~obs.mask).to(torch.int32), dim=1).int()
+        mk = obs.mask.cpu().numpy()
+        act = torch.tensor([choose(mk[b], b, int(steps[b])) if not (flags[b] & 1) else 0 for b in range(B)], dtype=torch.int32)
         env.step(act, leader=lead, n_followers=np.zeros(B, np.int32), followers=np.full((B, 4), -1, np.int16), observe=False)
         steps += (~(flags & 1).astype(bool)).astype(int)
     fin = H.gpu_final(env)
@@ -157,7 +169,7 @@ def test_individual_selection_mode(gpu_device, oracle_lib):
             o.task_update(); o.agent_update()                                # :168-169
             for a in ids:                                                    # :170
                 m = o.mask()                                                 # :175-179
-                o.agent_step(int(a), int(np.flatnonzero(m == 0)[0]))         # :185-186
+                o.agent_step(int(a), choose(m, b, n))                        # :185-186
                 o.task_update(); o.agent_update()                            # :187-188
                 n += 1
             finished = o.check_finished()                                    # :189
