@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Further reference-generated golden digests (run in the build container, where /root/reference is importable):
+
+    python tests/golden/make_golden_extra.py   ->  tests/golden/trace_hashes_extra.json
+
+Same harness as make_golden.py (the reference TaskEnv driven through the loop of worker.py:45-87 with the keyed
+choice protocol injected), on the axes the first set does not vary:
+
+  ranges      TaskEnv((10,20),(20,50),1,5,seed=s): per-seed sizes drawn by the reference itself (env/task_env.py:58-65)
+  mwt         env.max_waiting_time in {3, 25}   (RL_test.py / baselines set it after construction, like load_testset_env)
+  max_time    loop bound of worker.py:45 in {30, 250}
+  coalition   max_coalition_size 3 (requirements 1..3) and max_duration 2 / 0
+  wide        more agents than tasks
+
+Only numbers are stored (sizes, seeds, digests, rewards); no reference source.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+from make_golden import TaskEnv  # noqa: E402
+
+
+def run(env, seed_e, policy, max_time=100):
+    old = mg.MAX_TIME
+    mg.MAX_TIME = max_time
+    try:
+        return mg.rollout(env, seed_e, mg.POLICIES[policy])
+    finally:
+        mg.MAX_TIME = old
+
+
+def entry(env, tr, seed_e, policy, **kw):
+    ia = mg.instance_arrays(env)
+    d = dict(A=int(env.agents_num), T=int(env.tasks_num), policy=policy, seed_e=str(seed_e), sha256=mg.digest(tr),
+             n_steps=int(tr["n_steps"]), reward=float(tr["reward"]), n_finished=int(tr["finished"].sum()),
+             req_sum=int(ia["req"].sum()), dur0=float(ia["dur"][0]))
+    d.update(kw)
+    return d
+
+
+def main():
+    out = {}
+    # ranges: the reference draws (T, A) itself
+    for s in range(16):
+        env = TaskEnv((10, 20), (20, 50), 1, 5, seed=s)
+        se = mg.env_seed(5000, s)
+        pol = "random" if s % 2 == 0 else "nearest"
+        tr = run(env, se, pol)
+        out[f"ranges_s{s}"] = entry(env, tr, se, pol, kind="ranges", inst_seed=s)
+    # max_waiting_time
+    for (A, T) in ((10, 20), (20, 50)):
+        for mwt in (3, 25):
+            for s in (0, 1):
+                env = TaskEnv((A, A), (T, T), 1, 5, seed=s)
+                env.max_waiting_time = mwt
+                se = mg.env_seed(5100 + mwt, s)
+                tr = run(env, se, "random")
+                out[f"mwt{mwt}_{A}A{T}T_s{s}"] = entry(env, tr, se, "random", kind="fixed", inst_seed=s, max_waiting_time=mwt)
+    # loop bound
+    for (A, T) in ((10, 20), (20, 50)):
+        for mt in (30, 250):
+            env = TaskEnv((A, A), (T, T), 1, 5, seed=3)
+            se = mg.env_seed(5200 + mt, 3)
+            pol = "random" if mt == 30 else "nearest"
+            tr = run(env, se, pol, max_time=mt)
+            out[f"maxtime{mt}_{A}A{T}T"] = entry(env, tr, se, pol, kind="fixed", inst_seed=3, max_time=mt)
+    # coalition size / duration
+    for name, mcs, dur in (("coal3", 3, 5), ("dur2", 5, 2), ("dur0", 5, 0)):
+        for s in (0, 1):
+            env = TaskEnv((12, 12), (30, 30), 1, mcs, max_duration=dur, seed=s)
+            se = mg.env_seed(5300, s)
+            tr = run(env, se, "random")
+            out[f"{name}_12A30T_s{s}"] = entry(env, tr, se, "random", kind="fixed", inst_seed=s, max_coalition_size=mcs,
+                                               max_duration=dur)
+    # more agents than tasks
+    for (A, T) in ((30, 10), (64, 5)):
+        env = TaskEnv((A, A), (T, T), 1, 5, seed=2)
+        se = mg.env_seed(5400, A)
+        tr = run(env, se, "random")
+        out[f"wide_{A}A{T}T"] = entry(env, tr, se, "random", kind="fixed", inst_seed=2)
+    for k, v in out.items():
+        print(k, v["A"], v["T"], v["n_steps"], v["reward"], v["n_finished"], flush=True)
+    with open(os.path.join(HERE, "trace_hashes_extra.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,34 @@ def test_hashed_traces(oracle_lib):
         assert H.digest(out) == meta["sha256"], name
 
 
+def extra_instance(meta):
+    """Instance of an entry of trace_hashes_extra.json (tests/golden/make_golden_extra.py)."""
+    from dcmrta_amd.instances import generate_instance, generate_instance_ranges
+    if meta["kind"] == "ranges":
+        A, inst = generate_instance_ranges((10, 20), (20, 50), meta["inst_seed"])
+    else:
+        A = meta["A"]
+        inst = generate_instance(A, meta["T"], meta["inst_seed"], meta.get("max_coalition_size", 5), meta.get("max_duration", 5.0))
+    assert (A, len(inst["req"])) == (meta["A"], meta["T"])
+    assert int(inst["req"].sum()) == meta["req_sum"] and float(inst["dur"][0]) == meta["dur0"]
+    return A, inst
+
+
+def test_extra_hashed_traces(oracle_lib, golden_dir):
+    """Reference digests on the axes the first golden set keeps fixed: sizes drawn from (10,20)x(20,50) ranges,
+    max_waiting_time 3 / 25, loop bound 30 / 250, coalition size 3, durations 2 / 0, more agents than tasks."""
+    hashes = json.load(open(os.path.join(golden_dir, "trace_hashes_extra.json")))
+    assert len(hashes) >= 36
+    for name, meta in hashes.items():
+        A, inst = extra_instance(meta)
+        e = oracle_lib.OracleEnv(A, meta["T"], max_waiting_time=meta.get("max_waiting_time", 10.0),
+                                 max_time=meta.get("max_time", 100.0)).load(inst["depot"], inst["task_xy"], inst["req"], inst["dur"])
+        out = e.rollout(int(meta["seed_e"]), 0, POLICY[meta["policy"]], cap_steps=8192)
+        assert out["n_steps"] == meta["n_steps"] and out["reward"] == meta["reward"], name
+        assert int(out["finished"].sum()) == meta["n_finished"], name
+        assert H.digest(out) == meta["sha256"], name
+
+
 def test_testset_instances_rl_mode(oracle_lib, golden_dir):
     """The 50 shipped instances have per-task durations drawn U(0,5) (older generator): RL-mode digests."""
     from dcmrta_amd.instances import load_instances_npz
