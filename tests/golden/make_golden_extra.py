@@ -44,7 +44,88 @@ def entry(env, tr, seed_e, policy, **kw):
     return d
 
 
+def random_routes(rng, A, T, req):
+    """Random preset routes in the style of tools/sweep_replay.py: per task req +0..2 -0..1 visitors (sometimes too few,
+    sometimes surplus), visiting order sorted or shuffled, 5 % of the agents keep pre_set_route None, 80 % end with 0."""
+    r = [[] for _ in range(A)]
+    for t in range(T):
+        k = min(A, int(req[t]) + int(rng.integers(0, 3)) - int(rng.integers(0, 2)))
+        for a in rng.choice(A, size=max(k, 0), replace=False):
+            r[int(a)].append(t + 1)
+    routes = []
+    for a in range(A):
+        if rng.random() < 0.05:
+            routes.append(None)
+            continue
+        x = r[a]
+        if rng.random() < 0.5:
+            x = sorted(x)
+        else:
+            rng.shuffle(x)
+        routes.append([int(v) for v in x] + ([0] if rng.random() < 0.8 else []))
+    return routes
+
+
+class _Timeout(Exception):
+    pass
+
+
+def random_replays():
+    """execute_by_route (env/task_env.py:562-593) of the reference on random routes: known answers for the corners the
+    CTAS-D routes never reach (surplus visitors released early, too few visitors, None routes, shuffled order)."""
+    import contextlib
+    import copy
+    import io
+    import signal
+
+    def on_alarm(sig, frm):
+        raise _Timeout()
+    signal.signal(signal.SIGALRM, on_alarm)
+    rng = np.random.default_rng(99)
+    cases = []
+    shapes = [(20, 50, "testset")] * 6 + [(20, 3), (33, 7), (8, 7), (70, 3), (13, 20), (5, 37), (40, 20), (20, 20),
+                                          (10, 64), (64, 10), (3, 3), (2, 7)]
+    for ci, shp in enumerate(shapes):
+        for reactive in (False, True):
+            if len(shp) == 3:
+                A, T = 20, 50
+                env = mg.load_testset_env(ci)
+                src = dict(kind="testset", index=ci)
+            else:
+                A, T = shp
+                env = TaskEnv((A, A), (T, T), 1, 5, seed=100 + ci)
+                src = dict(kind="fixed", inst_seed=100 + ci)
+            ia = mg.instance_arrays(env)
+            routes = random_routes(rng, A, T, ia["req"])
+            env.reactive_planning = reactive
+            for a, r in enumerate(routes):
+                if r is not None:
+                    env.pre_set_route(copy.copy(r), a)
+            case = dict(A=A, T=T, reactive=reactive, routes=routes, req_sum=int(ia["req"].sum()), **src)
+            signal.alarm(120)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    env.execute_by_route("./", "x", False)
+                env.get_episode_reward(100)
+                fa = mg.final_arrays(env)
+                case["result"] = {k: np.asarray(fa[k]).tolist() for k in
+                                  ("metrics", "finished", "time_start", "time_finish", "task_wait", "agent_wait", "travel_dist",
+                                   "returned", "n_members", "route_len")}
+                case["status"] = "ok"
+            except TypeError:
+                case["status"] = "type_error"          # env/task_env.py:220 with pre_set_route None
+            except _Timeout:
+                case["status"] = "no_termination"      # the reference loops forever (SURVEY a-16); not a known answer
+            finally:
+                signal.alarm(0)
+            print("replay", ci, A, T, reactive, case["status"], case.get("result", {}).get("metrics", [None, None])[:2], flush=True)
+            cases.append(case)
+    with open(os.path.join(HERE, "replay_random.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+
+
 def main():
+    random_replays()
     out = {}
     # ranges: the reference draws (T, A) itself
     for s in range(16):

@@ -87,3 +87,32 @@ def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
         # env/task_env.py:567): the zero-decider guard shared by oracle and kernel ends such episodes identically.
         assert bool(flags[b] & 4) == bool(ref["truncated"]) == (reactive and T > 100)
         _check(out, b, ref, f"{A}A{T}T reactive={reactive} env{b}")
+
+
+def test_random_route_replays_known_answers(gpu_device, golden_dir):
+    """tests/golden/replay_random.json: the reference's own execute_by_route results on random routes (surplus visitors
+    released before they arrive -> non-monotone arrival lists, too few visitors, None routes, shuffled order)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from test_oracle_golden import random_replay_cases
+    n_ok = 0
+    for c, inst in random_replay_cases(golden_dir):
+        env = BatchedTaskEnv(1, c["A"], c["T"], device=gpu_device)
+        env.load_instances(inst["depot"][None], inst["task_xy"][None], inst["req"][None], inst["dur"][None])
+        env.load_routes([c["routes"]], member_cap=16)
+        out = env.execute_routes(reactive=c["reactive"])
+        flags = int(out["flags"].cpu().numpy()[0])
+        name = (c["A"], c["T"], c["reactive"])
+        if c["status"] == "type_error":
+            assert flags & 64, name
+        elif c["status"] == "no_termination":
+            assert flags & 4 and not flags & 64, name
+        else:
+            assert not flags & (4 | 16 | 64), name
+            for k in KEYS_EXACT:
+                exp = np.asarray(c["result"][k])
+                assert np.array_equal(out[k][0].cpu().numpy().astype(exp.dtype), exp), (name, k)
+            sm = out["summary"][0].cpu().numpy()
+            assert np.array_equal(sm[2:8], np.asarray(c["result"]["metrics"])), name
+            n_ok += 1
+        env.close()
+    assert n_ok >= 15

@@ -186,3 +186,44 @@ def test_micro_ties_have_several_groups(oracle_lib, golden_dir):
     ids, t = e.next_decision()
     assert list(ids) == [0, 1, 2, 3] and t == 0.25 / 0.2 + 5.0
     assert e.get_unique_group(ids) == [[2], [3], [1], [0]]
+
+
+def random_replay_cases(golden_dir):
+    """tests/golden/replay_random.json: (case, instance dict) pairs; instances from the test set or the seeded generator."""
+    from dcmrta_amd.instances import generate_instance, load_instances_npz
+    cases = json.load(open(os.path.join(golden_dir, "replay_random.json")))
+    ts, _ = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    out = []
+    for c in cases:
+        if c["kind"] == "testset":
+            inst = {k: ts[k][c["index"]] for k in ("depot", "task_xy", "req", "dur")}
+        else:
+            inst = generate_instance(c["A"], c["T"], c["inst_seed"])
+        assert int(inst["req"].sum()) == c["req_sum"]
+        out.append((c, inst))
+    return out
+
+
+def test_random_route_replays(oracle_lib, golden_dir):
+    """execute_by_route of the REFERENCE on random routes (surplus visitors that are released before they arrive, too few
+    visitors, pre_set_route None, shuffled visiting order; tests/golden/make_golden_extra.py): every terminal array bit
+    for bit, TypeError where the reference raises it, and the zero-decider guard where the reference never terminates."""
+    cases = random_replay_cases(golden_dir)
+    seen = {"ok": 0, "type_error": 0, "no_termination": 0}
+    for c, inst in cases:
+        o = oracle_lib.OracleEnv(c["A"], c["T"]).load(inst["depot"], inst["task_xy"], inst["req"], inst["dur"])
+        for a, r in enumerate(c["routes"]):
+            if r is not None:
+                o.pre_set_route(r, a)
+        try:
+            ref = o.execute_by_route(c["reactive"])
+            status = "no_termination" if ref["truncated"] else "ok"
+        except TypeError:
+            status = "type_error"
+        assert status == c["status"], (c["A"], c["T"], c["reactive"])
+        seen[status] += 1
+        if status == "ok":
+            for k, v in c["result"].items():
+                exp = np.asarray(v)
+                assert np.array_equal(np.asarray(ref[k]).astype(exp.dtype), exp, equal_nan=True), (c["A"], c["T"], c["reactive"], k)
+    assert seen["ok"] >= 15 and seen["type_error"] >= 10 and seen["no_termination"] >= 4
