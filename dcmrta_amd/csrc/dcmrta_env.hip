@@ -593,9 +593,17 @@ struct Sim {
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
                                                       const RouteLog* log = nullptr, int log_row = 0,
-                                                      bool no_grouping = false) const {
+                                                      bool no_grouping = false, bool check_mask = false) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
+        if (check_mask && action > 0) {
+            // host-supplied action on a masked task (feasible, or status <= 0 incl. the stale status of quirk Q3;
+            // env/task_env.py:192-200): the policy contract gives such actions probability 0 (attention.py:74-76), and a
+            // surplus member could be released before it arrives, which the compact state (arrival_time[-1] only) does
+            // not represent -- refuse loudly instead of diverging from the reference.
+            const uint32_t ik = uni(tinfo()[action - 1]);
+            if ((ik & T_FEAS) || (int)(int8_t)((ik >> 8) & 0xFF) <= 0) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
+        }
         AMask rest = gm0;
         am_clear(rest, leader);                                               // :328 group.remove(leader)
         int rlen = am_count(rest);
@@ -848,7 +856,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e * LP.A, (mode & DCM_PARAM_NO_GROUPING) != 0);
+                                &log, e * LP.A, (mode & DCM_PARAM_NO_GROUPING) != 0, true);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;

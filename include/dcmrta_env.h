@@ -53,8 +53,8 @@ typedef enum {
 #define DCM_FLAG_DONE 1u       /* episode over (terminal box of worker.py:87) */
 #define DCM_FLAG_FINISHED 2u   /* env.finished is True (env/task_env.py:366-373) */
 #define DCM_FLAG_TRUNCATED 4u  /* zero-decider guard fired (the reference would spin) */
-#define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T] */
-#define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members (masked action chosen) */
+#define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T], or a task the mask forbids (feasible / status <= 0) */
+#define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members / injected follower count too large */
 #define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
 #define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 

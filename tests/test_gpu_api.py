@@ -61,12 +61,31 @@ def test_error_flags_freeze_only_the_offending_env(gpu_device):
     assert obs.leader[1] == -1 and obs.mask[1].cpu().tolist() == [False] + [True] * 9   # inactive rows: only the depot unmasked
     # injected leader that is not deciding
     obs2 = env.observe(leader=np.array([0, -1, -1, 0], np.int32))
-    env.step(torch.ones(4, dtype=torch.int32, device=gpu_device), leader=np.array([-1, -1, -1, 5], np.int32), observe=False)
+    valid = torch.argmax((~obs2.mask).to(torch.int32), dim=1).int()                  # first unmasked action per env
+    env.step(valid, leader=np.array([-1, -1, -1, 5], np.int32), observe=False)
     # agent 5 decided at t=0 unless it already left with a previous leader; either it moved or BAD_LEADER is raised
     st = env.status()["flags"].cpu().numpy()
     assert st[3] in (0, _lib.FLAG_BAD_LEADER | _lib.FLAG_DONE)
     nan_rows = torch.isnan(env.summary()[:, 0]).cpu().numpy()
     assert nan_rows.all()   # nobody finished an episode yet -> summary rows are NaN
+
+
+def test_masked_task_action_is_refused(gpu_device):
+    """A host-supplied action on a task the mask forbids (worker.py:57-61) sets BAD_ACTION and freezes that env only."""
+    from dcmrta_amd import _lib
+    from dcmrta_amd.choice import env_seeds
+    env, _ = _mk(3, 6, 9, gpu_device)
+    obs = env.reset(env_seeds(5, 0, 3))
+    one = torch.ones(3, dtype=torch.int32, device=gpu_device)
+    obs = env.step(one)                                  # task 0 gets exactly its requirement -> status 0 -> masked
+    assert obs.mask[:, 1].all() and not env.status()["flags"].cpu().numpy().any()
+    act = one.clone()
+    unmasked = [int(np.flatnonzero(~obs.mask[b].cpu().numpy())[0]) for b in range(3)]
+    act[0], act[2] = unmasked[0], unmasked[2]            # env 1 repeats the now-masked action
+    obs = env.step(act)
+    flags = env.status()["flags"].cpu().numpy()
+    assert flags[1] == (_lib.FLAG_BAD_ACTION | _lib.FLAG_DONE) and flags[0] == 0 and flags[2] == 0
+    assert obs.active.cpu().tolist() == [True, False, True]
 
 
 def test_api_state_errors(gpu_device):
