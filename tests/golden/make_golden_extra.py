@@ -11,6 +11,9 @@ choice protocol injected), on the axes the first set does not vary:
   max_time    loop bound of worker.py:45 in {30, 250}
   coalition   max_coalition_size 3 (requirements 1..3) and max_duration 2 / 0
   wide        more agents than tasks
+  coincident  tasks sharing coordinates, a task on the depot
+
+and replay_random.json: the reference's execute_by_route on random preset routes.
 
 Only numbers are stored (sizes, seeds, digests, rewards); no reference source.
 """
@@ -35,9 +38,24 @@ def run(env, seed_e, policy, max_time=100):
         mg.MAX_TIME = old
 
 
+OBS_KEYS = ("leader", "action", "now", "mask", "agents_obs", "tasks_obs", "metrics", "finished", "time_start", "travel_dist",
+            "agent_wait", "task_wait")
+
+
+def digest_obs(tr):
+    """Digest over what the lockstep API hands back at every decision (no follower lists): the GPU parity test
+    recomputes it from the device outputs alone."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in OBS_KEYS:
+        h.update(np.ascontiguousarray(tr[k]).tobytes())
+    return h.hexdigest()
+
+
 def entry(env, tr, seed_e, policy, **kw):
     ia = mg.instance_arrays(env)
     d = dict(A=int(env.agents_num), T=int(env.tasks_num), policy=policy, seed_e=str(seed_e), sha256=mg.digest(tr),
+             sha256_obs=digest_obs(tr),
              n_steps=int(tr["n_steps"]), reward=float(tr["reward"]), n_finished=int(tr["finished"].sum()),
              req_sum=int(ia["req"].sum()), dur0=float(ia["dur"][0]))
     d.update(kw)
@@ -125,7 +143,8 @@ def random_replays():
 
 
 def main():
-    random_replays()
+    if "--skip-replays" not in sys.argv:
+        random_replays()
     out = {}
     # ranges: the reference draws (T, A) itself
     for s in range(16):
@@ -165,6 +184,30 @@ def main():
         se = mg.env_seed(5400, A)
         tr = run(env, se, "random")
         out[f"wide_{A}A{T}T"] = entry(env, tr, se, "random", kind="fixed", inst_seed=2)
+    # coincident locations: tasks sharing coordinates (agents deciding there at the same time form ONE group, since
+    # get_unique_group looks at locations only, env/task_env.py:291-298) and a task on top of the depot.  The instance
+    # arrays are stored with the digest (they are not what the seeded generator would produce).
+    coincident = {}
+    for s in range(6):
+        A, T = (8, 12) if s < 3 else (20, 30)
+        env = TaskEnv((A, A), (T, T), 1, 5, seed=200 + s)
+        rng = np.random.default_rng(300 + s)
+        for i in range(T):
+            j = int(rng.integers(0, 4))
+            if j < i and rng.random() < 0.6:
+                env.task_dic[i]["location"] = env.task_dic[j]["location"].copy()      # equal value, distinct array
+        env.task_dic[T - 1]["location"] = np.array(env.depot["location"], dtype=np.float64).copy()
+        if s % 2:
+            for i in range(T):
+                env.task_dic[i]["requirements"] = np.array([1 + i % 2])
+                env.task_dic[i]["status"] = np.array([1 + i % 2])
+        env.clear_decisions()
+        ia = mg.instance_arrays(env)
+        se = mg.env_seed(5500, s)
+        tr = run(env, se, "random")
+        e = entry(env, tr, se, "random", kind="arrays")
+        e.update(depot=ia["depot"].tolist(), task_xy=ia["task_xy"].tolist(), req=ia["req"].tolist(), dur=ia["dur"].tolist())
+        out[f"coincident_s{s}"] = e
     for k, v in out.items():
         print(k, v["A"], v["T"], v["n_steps"], v["reward"], v["n_finished"], flush=True)
     with open(os.path.join(HERE, "trace_hashes_extra.json"), "w") as f:

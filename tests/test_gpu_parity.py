@@ -198,32 +198,42 @@ def test_hashed_traces(gpu_device):
             assert int(fin[b]["n_finished"]) == meta["n_finished"], name
 
 
-def _trace_with_followers(env, seeds):
-    """Lockstep run under the keyed random policy, with the follower draws the digest also covers reconstructed from
-    the protocol (members = [leader] + followers, drawn without replacement from the rest of the group)."""
-    return H.run_lockstep(env, seeds, lambda b, i, mask, l: H.host_random_action(mask, int(seeds[b]), i))
+OBS_KEYS = ("leader", "action", "now", "mask", "agents_obs", "tasks_obs", "metrics", "finished", "time_start", "travel_dist",
+            "agent_wait", "task_wait")
+
+
+def _digest_obs(tr):
+    import hashlib
+    h = hashlib.sha256()
+    for k in OBS_KEYS:
+        h.update(np.ascontiguousarray(tr[k]).tobytes())
+    return h.hexdigest()
 
 
 def test_extra_hashed_traces(gpu_device, golden_dir):
     """tests/golden/trace_hashes_extra.json (reference digests over ranges-drawn sizes, max_waiting_time 3/25, loop bound
-    30/250, coalition size 3, durations 2/0, more agents than tasks): step count, reward and finished count of the HIP
-    path, lockstep API and persistent kernel, must equal the reference's.  The range-drawn instances run as ONE ragged batch."""
+    30/250, coalition size 3, durations 2/0, more agents than tasks, coincident task locations): the sha256 over every
+    per-decision output of the lockstep API (leader, action, event time, mask, both observation tensors) and the terminal
+    arrays must equal the reference's; the persistent kernel must end in the same state.  The range-drawn instances run
+    as ONE ragged batch."""
     from test_oracle_golden import extra_instance
     hashes = json.load(open(os.path.join(golden_dir, "trace_hashes_extra.json")))
     groups = {}
     for name, meta in hashes.items():
         if meta["policy"] != "random":
-            continue
-        key = ("ranges",) if meta["kind"] == "ranges" else (meta["A"], meta["T"], meta.get("max_waiting_time", 10.0),
-                                                           meta.get("max_time", 100.0))
+            continue  # nearest-policy traces need the recorded actions (only digests are committed)
+        key = ("ranges",) if meta["kind"] == "ranges" else (meta["A"], meta["T"], float(meta.get("max_waiting_time", 10.0)),
+                                                           float(meta.get("max_time", 100.0)))
         groups.setdefault(key, []).append((name, meta))
-    assert len(groups) >= 9
+    assert len(groups) >= 10
     for key, items in groups.items():
         insts = [extra_instance(m) for _, m in items]
         B = len(items)
+        nA = np.array([a for a, _ in insts], np.int32)
+        nT = np.array([len(i["req"]) for _, i in insts], np.int32)
         if key == ("ranges",):
             A, T, mwt, mt = 20, 50, 10.0, 100.0
-            kw = dict(n_agents=np.array([a for a, _ in insts], np.int32), n_tasks=np.array([len(i["req"]) for _, i in insts], np.int32))
+            kw = dict(n_agents=nA, n_tasks=nT)
         else:
             (A, T, mwt, mt), kw = key, {}
         pad = lambda x, n: np.concatenate([x, np.ones((n - len(x),) + x.shape[1:], x.dtype)])
@@ -231,12 +241,21 @@ def test_extra_hashed_traces(gpu_device, golden_dir):
         env.load_instances(np.stack([i["depot"] for _, i in insts]), np.stack([pad(i["task_xy"], T) for _, i in insts]),
                            np.stack([pad(i["req"], T) for _, i in insts]), np.stack([pad(i["dur"], T) for _, i in insts]), **kw)
         seeds = np.array([int(m["seed_e"]) for _, m in items], np.uint64)
-        got = _trace_with_followers(env, seeds)
+        got = H.run_lockstep(env, seeds, lambda b, i, mask, l: H.host_random_action(mask[:nT[b] + 1], int(seeds[b]), i))
         fin = H.gpu_final(env)
         env.reset(seeds, observe=False)
         ksteps = env.rollout_random(1).cpu().numpy()
         kfin = H.gpu_final(env)
         for b, (name, meta) in enumerate(items):
-            assert got[b]["n_steps"] == meta["n_steps"] == ksteps[b], name
-            assert float(fin[b]["reward"]) == meta["reward"] == float(kfin[b]["reward"]), name
-            assert int(fin[b]["n_finished"]) == meta["n_finished"] == int(kfin[b]["n_finished"]), name
+            a, t = int(nA[b]), int(nT[b])
+            g, f = got[b], fin[b]
+            assert g["n_steps"] == meta["n_steps"] == ksteps[b], name
+            tr = dict(leader=g["leader"], action=g["action"], now=g["now"], mask=g["mask"][:, :t + 1],
+                      agents_obs=g["agents_obs"][:, :a], tasks_obs=g["tasks_obs"][:, :t + 1], metrics=f["metrics"],
+                      finished=f["finished"][:t].astype(np.uint8), time_start=f["time_start"][:t], travel_dist=f["travel_dist"][:a],
+                      agent_wait=f["agent_wait"][:a], task_wait=f["task_wait"][:t])
+            assert _digest_obs(tr) == meta["sha256_obs"], name
+            assert float(f["reward"]) == meta["reward"] == float(kfin[b]["reward"]), name
+            assert int(f["n_finished"]) == meta["n_finished"] == int(kfin[b]["n_finished"]), name
+            for k in ("time_start", "travel_dist", "agent_wait", "task_wait", "metrics"):
+                assert np.array_equal(f[k], kfin[b][k], equal_nan=True), (name, k)

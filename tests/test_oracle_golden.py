@@ -61,6 +61,10 @@ def extra_instance(meta):
     from dcmrta_amd.instances import generate_instance, generate_instance_ranges
     if meta["kind"] == "ranges":
         A, inst = generate_instance_ranges((10, 20), (20, 50), meta["inst_seed"])
+    elif meta["kind"] == "arrays":           # hand-modified instance (coincident locations): arrays stored with the digest
+        A = meta["A"]
+        inst = dict(depot=np.array(meta["depot"]), task_xy=np.array(meta["task_xy"]), req=np.array(meta["req"], np.int32),
+                    dur=np.array(meta["dur"]))
     else:
         A = meta["A"]
         inst = generate_instance(A, meta["T"], meta["inst_seed"], meta.get("max_coalition_size", 5), meta.get("max_duration", 5.0))
@@ -71,9 +75,10 @@ def extra_instance(meta):
 
 def test_extra_hashed_traces(oracle_lib, golden_dir):
     """Reference digests on the axes the first golden set keeps fixed: sizes drawn from (10,20)x(20,50) ranges,
-    max_waiting_time 3 / 25, loop bound 30 / 250, coalition size 3, durations 2 / 0, more agents than tasks."""
+    max_waiting_time 3 / 25, loop bound 30 / 250, coalition size 3, durations 2 / 0, more agents than tasks, tasks with
+    coincident coordinates / on the depot (one group per LOCATION, env/task_env.py:291-298)."""
     hashes = json.load(open(os.path.join(golden_dir, "trace_hashes_extra.json")))
-    assert len(hashes) >= 36
+    assert len(hashes) >= 42
     for name, meta in hashes.items():
         A, inst = extra_instance(meta)
         e = oracle_lib.OracleEnv(A, meta["T"], max_waiting_time=meta.get("max_waiting_time", 10.0),
