@@ -1082,15 +1082,20 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     }
     hipError_t e3 = hipMemset(h->state, 0, bytes);
     if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); (void)hipFree(h->ablog); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
-    // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS
-    const int lds = (int)h->L.lds_bytes();
+    // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS.  The limit is a
+    // per-function, per-device attribute shared by every handle of the process, so it only ever grows: a later, smaller
+    // env must not lower it under an earlier handle's launches.
+    static int lds_limit[64] = {0};
+    const int dev_slot = params->device & 63;
+    int lds = (int)h->L.lds_bytes();
+    if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
+    lds_limit[dev_slot] = lds;
 #define SET_ATTR(CA, CT)                                                                                             \
     (void)hipFuncSetAttribute((const void*)k_reset<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
     (void)hipFuncSetAttribute((const void*)k_observe<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
     (void)hipFuncSetAttribute((const void*)k_step<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
     (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-    DISPATCH_SHAPE(params->n_agents, params->n_tasks, SET_ATTR);
-    SET_ATTR(0, 0);
+    SET_ATTR(20, 50); SET_ATTR(50, 200); SET_ATTR(100, 500); SET_ATTR(0, 0);
 #undef SET_ATTR
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<20, 50>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

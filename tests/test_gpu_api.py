@@ -88,6 +88,27 @@ def test_masked_task_action_is_refused(gpu_device):
     assert obs.active.cpu().tolist() == [True, False, True]
 
 
+def test_handles_of_different_shapes_coexist(gpu_device, oracle_lib):
+    """The dynamic-LDS limit is a per-kernel attribute shared by all handles: creating a small env after a large one
+    must not break the large one's launches (runtime-shape kernels, 100A/300T needs > 64 KiB of LDS)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    big_inst, small_inst = generate_batch(2, 100, 300, base_seed=5), generate_batch(2, 5, 8, base_seed=5)
+    big = BatchedTaskEnv(2, 100, 300, device=gpu_device).load_instances(**big_inst)
+    small = BatchedTaskEnv(2, 5, 8, device=gpu_device).load_instances(**small_inst)
+    seeds = env_seeds(1, 0, 2)
+    for env, inst, (A, T) in ((big, big_inst, (100, 300)), (small, small_inst, (5, 8)), (big, big_inst, (100, 300))):
+        env.reset(seeds, observe=False)
+        steps = env.rollout_random(1).cpu().numpy()
+        fin = H.gpu_final(env)
+        for b in range(2):
+            ref = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b]).rollout(
+                int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, cap_steps=100000, record=False)
+            assert steps[b] == ref["n_steps"]
+            H.assert_final_matches(fin[b], ref, f"{A}A{T}T env{b}")
+
+
 def test_api_state_errors(gpu_device):
     from dcmrta_amd import _lib
     from dcmrta_amd.batched_env import BatchedTaskEnv

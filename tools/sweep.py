@@ -53,15 +53,21 @@ for it in range(n_shapes):
         if mode == "lockstep":
             if it % 4 and not (ragged and it % 2):
                 continue
-            obs = env.reset(seeds)
-            cnt = np.zeros(B, np.int64)
-            while bool(obs.active.any()):
-                act_host = obs.active.cpu().numpy()
-                mk = obs.mask.cpu().numpy().astype(np.uint8)
-                a = np.array([H.host_random_action(mk[b], int(seeds[b]), int(cnt[b])) if act_host[b] else 0 for b in range(B)], np.int32)
-                cnt += act_host
-                obs = env.step(a)
-            steps = cnt
+            # every per-decision output (leader, event time, mask, both observation tensors) against the oracle's trace
+            got = H.run_lockstep(env, seeds, lambda b, i, m, l: H.host_random_action(m, int(seeds[b]), i))
+            steps = np.array([g["n_steps"] for g in got], np.int64)
+            for b in range(B):
+                a, t = int(nA[b]), int(nT[b])
+                o = oracle.OracleEnv(a, t, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+                ref = o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=True)
+                g = got[b]
+                ok = (g["n_steps"] == ref["n_steps"] and np.array_equal(g["leader"], ref["leader"]) and np.array_equal(g["now"], ref["now"])
+                      and np.array_equal(g["mask"][:, :t + 1], ref["mask"]) and np.array_equal(g["agents_obs"][:, :a], ref["agents_obs"])
+                      and np.array_equal(g["tasks_obs"][:, :t + 1], ref["tasks_obs"])
+                      and (g["mask"][:, t + 1:] == 1).all() and (g["agents_obs"][:, a:] == -1).all() and (g["tasks_obs"][:, t + 1:] == -1).all())
+                if not ok:
+                    bad += 1
+                    print("MISMATCH per-step outputs", A, T, mwt, base, b, "ragged", ragged, flush=True)
         else:
             env.reset(seeds, observe=False)
             steps = env.rollout_random(1).cpu().numpy()
