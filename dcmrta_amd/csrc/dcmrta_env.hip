@@ -155,22 +155,27 @@ struct Sim {
             const bool le0 = status <= 0;                                    // :254
             const bool ok = le0 && (mx - mn <= mwt);                         // :255
             const double thr = mx - mwt;                                     // :262
-            uint32_t spread = 0, q1 = 0;
-            bool prev = false;
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                spread |= (av[j] <= thr) ? (1u << j) : 0u;                   // :262-265
-                // :268-271 iterates task['members'] while removing from it: after a removal the element
-                // that slides into the freed slot is skipped by the list iterator (quirk Q1).
-                const bool e = !prev && (now - av[j] >= mwt);                // :269
-                q1 |= e ? (1u << j) : 0u;
-                prev = e;
-            }
-            const uint32_t drop = feas0 ? 0u : (le0 ? (ok ? 0u : spread) : q1);
+            // Does any member leave?  Spread branch (:262): some av[j] <= thr  <=>  mn <= thr.  Waiting branch (:269): some
+            // now - av[j] >= mwt  <=>  now - mn >= mwt (fp subtraction and comparison are monotone in av[j]; the first
+            // expired member is never skipped by Q1).  NaN (no members) makes both false.  The per-slot masks are only
+            // built inside this rare divergent branch.
+            const bool any_drop = !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
             if (!feas0) {
                 if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; }  // :256-258
                 int nn = n;
-                if (drop) {  // rare: compact the surviving members in order
+                if (any_drop) {  // rare: compact the surviving members in order
+                    uint32_t spread = 0, q1 = 0;
+                    bool prev = false;
+#pragma unroll
+                    for (int j = 0; j < M; j++) {
+                        spread |= (av[j] <= thr) ? (1u << j) : 0u;           // :262-265
+                        // :268-271 iterates task['members'] while removing from it: after a removal the element
+                        // that slides into the freed slot is skipped by the list iterator (quirk Q1).
+                        const bool e = !prev && (now - av[j] >= mwt);        // :269
+                        q1 |= e ? (1u << j) : 0u;
+                        prev = e;
+                    }
+                    const uint32_t drop = le0 ? spread : q1;
                     const uint64_t ids = mids()[t];
                     uint64_t nids = 0;
                     int k = 0;
@@ -923,10 +928,25 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
             const uint64_t k1 = mix64(gd);
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
+#ifdef DCM_DUP_LEADER   // instruction-count probes (tools/variants.py + VARIANTS_PMC): run one pure phase twice
+            { AMask g2; volatile int l2 = S.pick_leader(h, lane, -1, k1 ^ 1, g2); (void)l2; }
+#endif
             PH_MARK(0);
             S.observe(h, lane, leader, ag, tk, mk);
+#ifdef DCM_DUP_OBSERVE
+            WSYNC(); S.observe(h, lane, leader, ag, tk, mk);
+#endif
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
+#ifdef DCM_DUP_ACTION
+            { volatile int a2 = S.pick_random_action(lane, k1 ^ 1); (void)a2; }
+#endif
+#ifdef DCM_DUP_TU
+            WSYNC(); S.task_update(h, P, lane); WSYNC();
+#endif
+#ifdef DCM_DUP_AU
+            WSYNC(); S.agent_update(h, P, lane); WSYNC();
+#endif
             PH_MARK(2);
             S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS);
             gd += GAMMA;
