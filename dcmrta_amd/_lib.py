@@ -18,6 +18,7 @@ MAX_AGENTS = 128
 MAX_TASKS = 1023
 
 FLAG_DONE, FLAG_FINISHED, FLAG_TRUNCATED, FLAG_BAD_ACTION, FLAG_OVERFLOW, FLAG_BAD_LEADER, FLAG_TYPE_ERROR = 1, 2, 4, 8, 16, 32, 64
+FLAG_WAIT_ORDER = 128   # informational: abandonment log of an agent overflowed, waiting sums added in a different order
 
 
 class DcmParams(C.Structure):

@@ -239,7 +239,8 @@ struct Sim {
 
     // ------------------------------------------------------------------------------ terminal
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
-    __device__ void compute_waits(double now, double mwt, int lane) const {
+    // Returns true when some agent's abandonment log overflowed (see DCM_FLAG_WAIT_ORDER).
+    __device__ bool compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A();
         const int TW = (int)L().twords();
 #ifdef DCM_PROFILE_PHASES
@@ -278,9 +279,11 @@ struct Sim {
             for (int i = lane; i < A_ * AB_CAP * 2 / 16; i += WAVE) dst[i] = src[i];
         }
         WSYNC();
+        bool over = false;
         for (int a = lane; a < A_; a += WAVE) {
             const uint32_t nab = ainfo()[a] >> 16;
             const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+            over = over || nab > (uint32_t)AB_CAP;
             uint16_t* my = absort() + a * AB_CAP;
             for (int i = 1; i < nl; i++) {                                   // in-place insertion sort by task id
                 const uint16_t v = my[i];
@@ -318,17 +321,18 @@ struct Sim {
         if (lane == 0) atomicAdd(&g_phase_cycles[13], __builtin_readcyclecounter() - pt1);
 #endif
         WSYNC();
+        return __any(over);
     }
 
     // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
     // (header fields are passed by value: a by-reference Hdr would force the caller's header into scratch memory)
 #ifdef DCM_INLINE_TERMINAL
-    __device__ __forceinline__ void terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
+    __device__ __forceinline__ bool terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
 #else
-    __device__ __noinline__ void terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
+    __device__ __noinline__ bool terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
 #endif
         WSYNC();
-        compute_waits(now, mwt, lane);
+        const bool over = compute_waits(now, mwt, lane);
         const int T_ = T(), A_ = A();
         int nfin = 0;
         for (int t0 = 0; t0 < T_; t0 += WAVE) {
@@ -354,16 +358,17 @@ struct Sim {
             row[3] = now;                              // makespan :104
             row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
         }
+        return over;
     }
     __device__ __forceinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt = __builtin_readcyclecounter();
 #endif
-        terminal_metrics(h.now, P.mwt, lane, row);
+        const bool over = terminal_metrics(h.now, P.mwt, lane, row);
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[15], __builtin_readcyclecounter() - pt);
 #endif
-        h.flags |= DCM_FLAG_DONE;
+        h.flags |= DCM_FLAG_DONE | (over ? DCM_FLAG_WAIT_ORDER : 0u);
         if (lane == 0) ((Hdr*)base)->episodes += 1;   // cold header fields stay in the LDS record
         h.cur_group = 0;
     }

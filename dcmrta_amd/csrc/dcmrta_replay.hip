@@ -375,9 +375,11 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
     }
     // :358-364 per agent in the reference's order: tasks ascending, member term first, then +max_waiting_time per
     // entry of the agent in that task's abandoned_agent list (entries from the abandonment log, sorted by task id)
+    bool over = false;
     for (int a = lane; a < A; a += WAVE) {
         const uint32_t nab = R.ainfo()[a] >> 16;
         const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+        over = over || nab > (uint32_t)AB_CAP;
         uint16_t* my = R.ablog() + a * AB_CAP;
         for (int i = 1; i < nl; i++) {
             const uint16_t v = my[i];
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
         s += (double)(nab - (uint32_t)nl) * mwt;
         R.aw()[a] = s;
     }
+    if (__any(over)) flags |= DCM_FLAG_WAIT_ORDER;
     WSYNC();
     int nfin = 0;
     for (int t0 = 0; t0 < T; t0 += WAVE) {

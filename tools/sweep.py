@@ -23,14 +23,23 @@ rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2026)
 TASK_KEYS = ("finished", "feasible", "time_start", "time_finish", "task_wait", "n_members", "n_abandoned")
 AGENT_KEYS = ("travel_dist", "returned", "agent_wait")
 bad, checked, t0 = 0, 0, time.time()
+wait_order = 0
 for it in range(n_shapes):
     A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
     T = int(rng.choice([1, 2, 7, 20, 37, 50, 63, 64, 65, 100, 128, 129, 200, 300]))
     mwt = float(rng.choice([10.0, 10.0, 3.0, 25.0]))
+    max_time = float(rng.choice([100.0, 100.0, 30.0, 250.0]))
     base = int(rng.integers(0, 1 << 30))
     inst = generate_batch(B, A, T, base_seed=base)
     if it % 3 == 0:   # non-constant durations like the shipped test set (U(0,5))
         inst["dur"] = rng.random((B, T)) * 5.0
+    elif it % 7 == 1:   # zero / long durations
+        inst["dur"] = np.full((B, T), float(rng.choice([0.0, 20.0])))
+    if it % 5 == 4:     # smaller coalitions (max_coalition_size 1..3) or all-5 requirements
+        inst["req"] = rng.integers(1, int(rng.integers(1, 4)) + 1, (B, T)).astype(np.int32) if it % 2 else np.full((B, T), 5, np.int32)
+    if it % 11 == 5:    # coincident task locations / a task on the depot
+        inst["task_xy"][:, 1::2] = inst["task_xy"][:, 0:1]
+        inst["task_xy"][:, -1] = inst["depot"]
     seeds = env_seeds(base ^ 0x5A5A, 0, B)
     ragged = (it % 5 == 2)   # every env of the batch gets its own (A_e, T_e) <= (A, T): dcm_load_instances_ragged
     nA = rng.integers(1, A + 1, B).astype(np.int32) if ragged else np.full(B, A, np.int32)
@@ -40,7 +49,7 @@ for it in range(n_shapes):
     refs = []
     for b in range(B):
         a, t = int(nA[b]), int(nT[b])
-        o = oracle.OracleEnv(a, t, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+        o = oracle.OracleEnv(a, t, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
         refs.append(o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False))
     for mode in ("rollout", "fast", "lockstep"):
         if mode == "fast":
@@ -49,7 +58,7 @@ for it in range(n_shapes):
             os.environ["DCM_FAST_ROLLOUT"] = "1"
         else:
             os.environ.pop("DCM_FAST_ROLLOUT", None)
-        env = BatchedTaskEnv(B, A, T, max_waiting_time=mwt).load_instances(**inst)
+        env = BatchedTaskEnv(B, A, T, max_waiting_time=mwt, max_time=max_time).load_instances(**inst)
         if mode == "lockstep":
             if it % 4 and not (ragged and it % 2):
                 continue
@@ -58,7 +67,7 @@ for it in range(n_shapes):
             steps = np.array([g["n_steps"] for g in got], np.int64)
             for b in range(B):
                 a, t = int(nA[b]), int(nT[b])
-                o = oracle.OracleEnv(a, t, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+                o = oracle.OracleEnv(a, t, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
                 ref = o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=True)
                 g = got[b]
                 ok = (g["n_steps"] == ref["n_steps"] and np.array_equal(g["leader"], ref["leader"]) and np.array_equal(g["now"], ref["now"])
@@ -80,10 +89,16 @@ for it in range(n_shapes):
                     f[k] = f[k][:nT[b]]
                 for k in AGENT_KEYS:
                     f[k] = f[k][:nA[b]]
+                if f["flags"] & 128:   # DCM_FLAG_WAIT_ORDER: >16 abandonments of one agent, sums equal within rounding only
+                    assert np.allclose(f["agent_wait"], refs[b]["agent_wait"], rtol=1e-12, atol=0) and \
+                        np.isclose(f["metrics"][3], refs[b]["metrics"][3], rtol=1e-12, atol=0)
+                    f["agent_wait"] = refs[b]["agent_wait"]
+                    f["metrics"] = f["metrics"].copy(); f["metrics"][3] = refs[b]["metrics"][3]
+                    wait_order += 1
                 H.assert_final_matches(f, refs[b], f"{mode} {A}A{T}T mwt={mwt} base={base} env{b} ragged={ragged}")
             except AssertionError as ex:
                 bad += 1
                 print("MISMATCH", mode, A, T, mwt, base, b, str(ex)[:200], flush=True)
             checked += 1
         env.close()
-print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {time.time() - t0:.0f} s")
