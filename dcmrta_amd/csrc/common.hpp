@@ -269,8 +269,17 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "");
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) return dcm::fail(DCM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
-#define CHECK_ENV(env) \
+#define CHECK_HANDLE(env) \
     if (!(env)) return dcm::fail(DCM_ERR_INVALID, "null env handle")
+// every launching entry point runs on the CALLER's current device: refuse loudly when that is not the handle's device
+// (device pointers of one GPU dereferenced by a kernel on another fault asynchronously and far from the cause)
+#define CHECK_ENV(env)                                                                                        \
+    do {                                                                                                      \
+        if (!(env)) return dcm::fail(DCM_ERR_INVALID, "null env handle");                                     \
+        int _cur = -1;                                                                                        \
+        if (hipGetDevice(&_cur) != hipSuccess || _cur != (env)->p.device)                                     \
+            return dcm::fail(DCM_ERR_STATE, "the current HIP device is not the device this env was created on"); \
+    } while (0)
 #define LAUNCH_OK() HIP_TRY(hipGetLastError())
 #define GRID(env) dim3((env)->p.n_envs), dim3(dcm::WAVE)
 

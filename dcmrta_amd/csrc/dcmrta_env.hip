@@ -1198,7 +1198,7 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
 }
 
 int dcm_set_route_log(dcm_env* env, int16_t* route_task, double* route_arrival, int32_t* route_len, int32_t cap) {
-    CHECK_ENV(env);
+    CHECK_HANDLE(env);
     const bool off = !route_task && !route_arrival && !route_len;
     if (!off && (!route_task || !route_arrival || !route_len || cap < 1))
         return fail(DCM_ERR_INVALID, "dcm_set_route_log: give all three arrays and cap >= 1, or all NULL");
@@ -1302,7 +1302,7 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
 }
 
 int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
-    CHECK_ENV(env);
+    CHECK_HANDLE(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
     *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double) +
                  (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t);
@@ -1354,7 +1354,7 @@ int dcm_prof_read(unsigned long long* out16, int reset) {
 #endif
 
 int dcm_record_bytes(dcm_env* env, size_t* bytes_out) {
-    CHECK_ENV(env);
+    CHECK_HANDLE(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
     *bytes_out = env->L.rec_bytes();
     return DCM_OK;

@@ -14,7 +14,9 @@
  *  - every call takes the hipStream_t to enqueue on (torch.cuda.current_stream().cuda_stream,
  *    passed as void*) and is asynchronous with respect to the host.
  *  - a handle is bound to one device and is not thread-safe (one host thread per GPU,
- *    like one env per Ray actor in runner.py:74).
+ *    like one env per Ray actor in runner.py:74).  Calls that launch work must be made with
+ *    that device current (hipSetDevice / torch.cuda.device): otherwise they fail with
+ *    DCM_ERR_STATE instead of launching on the wrong GPU.
  *  - there is NO CPU implementation behind this ABI: without a HIP device dcm_create fails.
  *
  * One "env step" = one leader decision in one env = one TaskEnv.step call
