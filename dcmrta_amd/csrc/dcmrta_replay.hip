@@ -92,58 +92,88 @@ struct Rep {
 
     // tinfo[t]: bits 0-7 requirements, 8-15 status (int8), 16-23 len(members), 24 feasible, 25 finished
 
-    // env/task_env.py:245-281 with up to MR members per task
-    __device__ void task_update(double now, double mwt, int lane, uint32_t& flags) const {
-        bool allf = true;
-        for (int t = lane; t < T; t += WAVE) {
-            uint32_t info = tinfo()[t];
-            if (!(info & T_FEAS)) {                                          // :249
-                const int req = info & 0xFF;
-                const int n = (info >> 16) & 0xFF;                           // :250
-                const int status = req - n;                                  // :252
-                uint32_t keep = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-                bool changed = false;
-                if (status <= 0) {                                           // :254
-                    double mx = marr()[t], mn = mx;
-                    for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
-                    if (mx - mn <= mwt) {                                    // :255
-                        ts()[t] = mx; tf()[t] = mx + tdur()[t]; info |= T_FEAS;   // :256-258
-                    } else {
-                        const double thr = mx - mwt;                         // :262
-                        for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }
-                    }
+    // env/task_env.py:245-281 for ONE task (lane-private); returns true when the call changed the member list or made the
+    // task feasible -- the only cases in which an immediate second call at the same `now` can change it again (a Q1-skipped
+    // member / stale status after the spread branch / `finished` of a task that has just become feasible, :273)
+    __device__ bool task_update_one(int t, double now, double mwt) const {
+        uint32_t info = tinfo()[t];
+        bool touched = false;
+        if (!(info & T_FEAS)) {                                              // :249
+            const int req = info & 0xFF;
+            const int n = (info >> 16) & 0xFF;                               // :250
+            const int status = req - n;                                      // :252
+            uint32_t keep = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+            bool changed = false;
+            if (status <= 0) {                                               // :254
+                double mx = marr()[t], mn = mx;
+                for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                if (mx - mn <= mwt) {                                        // :255
+                    ts()[t] = mx; tf()[t] = mx + tdur()[t]; info |= T_FEAS;  // :256-258
+                    touched = true;
                 } else {
-                    bool skip = false;                                       // :268-271 (quirk Q1)
-                    for (int j = 0; j < n; j++) {
-                        if (skip) { skip = false; continue; }
-                        if (now - marr()[j * T + t] >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
-                    }
+                    const double thr = mx - mwt;                             // :262
+                    for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }
                 }
-                int nn = n;
-                if (changed) {
-                    int k = 0;
-                    for (int j = 0; j < n; j++) {
-                        const uint32_t id = mid()[j * T + t];
-                        if (keep & (1u << j)) {
-                            if (k != j) { mid()[k * T + t] = (uint8_t)id; marr()[k * T + t] = marr()[j * T + t]; }
-                            k++;
-                        } else {
-                            const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
-                            if (nth < (uint32_t)AB_CAP) ablog()[id * AB_CAP + nth] = (uint16_t)t;
-                            if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
-                        }
-                    }
-                    tnab()[t] += (uint32_t)(n - k);
-                    nn = k;
+            } else {
+                bool skip = false;                                           // :268-271 (quirk Q1)
+                for (int j = 0; j < n; j++) {
+                    if (skip) { skip = false; continue; }
+                    if (now - marr()[j * T + t] >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
                 }
-                info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
-            } else if (now >= tf()[t]) {
-                info |= T_FIN;                                               // :273-274
             }
-            tinfo()[t] = info;
-            allf = allf && (info & T_FEAS);
+            int nn = n;
+            if (changed) {
+                int k = 0;
+                for (int j = 0; j < n; j++) {
+                    const uint32_t id = mid()[j * T + t];
+                    if (keep & (1u << j)) {
+                        if (k != j) { mid()[k * T + t] = (uint8_t)id; marr()[k * T + t] = marr()[j * T + t]; }
+                        k++;
+                    } else {
+                        const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
+                        if (nth < (uint32_t)AB_CAP) ablog()[id * AB_CAP + nth] = (uint16_t)t;
+                        if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
+                    }
+                }
+                tnab()[t] += (uint32_t)(n - k);
+                nn = k;
+                touched = true;
+            }
+            info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
+        } else if (now >= tf()[t]) {
+            info |= T_FIN;                                                   // :273-274
         }
-        const bool all_feasible = __all(allf);
+        tinfo()[t] = info;
+        return touched;
+    }
+
+    // task_update (:245-281).  only == -1: every task, like the reference.  only >= 0 / -2: the call that follows an
+    // agent_step at an unchanged `now` when the previous call reported redo == false -- then every task except the one the
+    // agent has just joined (`only`; -2 = it went to the depot) is at a fixed point of task_update and is skipped, which
+    // turns the T/64 lane passes of this call into one.  n_infeas carries the number of tasks that are not feasible
+    // (feasible_assignment never reverts), for np.all(feasible) of the depot check :279.
+    __device__ void task_update(double now, double mwt, int lane, int only, bool& redo, int& n_infeas) const {
+        bool touched = false;
+        if (only == -1) {
+            int infeas = 0;
+            for (int t0 = 0; t0 < T; t0 += WAVE) {
+                const int t = t0 + lane;
+                bool inf = false;
+                if (t < T) { touched = task_update_one(t, now, mwt) || touched; inf = !(tinfo()[t] & T_FEAS); }
+                infeas += __popcll(__ballot(inf));
+            }
+            n_infeas = infeas;
+        } else if (only >= 0) {
+            bool became = false;
+            if (lane == (only & 63)) {
+                const bool was = tinfo()[only] & T_FEAS;
+                touched = task_update_one(only, now, mwt);
+                became = !was && (tinfo()[only] & T_FEAS);
+            }
+            if (__any(became)) n_infeas -= 1;
+        }
+        redo = __any(touched);
+        const bool all_feasible = n_infeas == 0;
         WSYNC();
         for (int a = lane; a < A; a += WAVE) {                               // depot :277-280
             const uint32_t ai = ainfo()[a];
@@ -229,21 +259,22 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
     }
     double now = 0.0;
     uint32_t flags = 0;
-    bool finished_flag = false;
-    int visible = 0, guard = 0;
+    bool finished_flag = false, redo = true;
+    int visible = 0, guard = 0, n_infeas = T;
     int64_t steps = 0;
     const double mwt = P.mwt;                                                // :564
     // Guard (not in the reference): with reactive planning a depot agent whose next task id is beyond the hard
     // visibility cap of 100 re-decides at the same time forever (env/task_env.py:220-222,578-584); stop such envs.
     const int64_t step_cap = 64 * (int64_t)(A + T) + 4096;
     WSYNC();
-    // stage the next preset action of every agent into aw() (scratch until the terminal metrics)
-    auto stage_next = [&]() {
-        for (int a = lane; a < A; a += WAVE) {
-            const int len = R.plen()[a], head = R.phead()[a];
-            R.aw()[a] = (len > 0 && head < len) ? (double)my_routes[(size_t)a * route_cap + head] : 0.0;
-        }
-    };
+    // aw()[a] (scratch until the terminal metrics) holds the next preset action of agent a: staged once for everybody,
+    // then refreshed only for the agent that pops its route (its entry is the only one that changes), with the global
+    // load issued at the pop and consumed after the updates so that its latency hides behind task_update/agent_update
+    for (int a = lane; a < A; a += WAVE) {
+        const int len = R.plen()[a];
+        R.aw()[a] = (len > 0) ? (double)my_routes[(size_t)a * route_cap] : 0.0;
+    }
+    WSYNC();
     while (!finished_flag && now < P.cutoff) {                               // :565
         if (P.reactive) {                                                    // :566-567
             double v = py_floordiv(now, 10.0) * 20.0 + 20.0;
@@ -267,9 +298,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
             const int a = i * 64 + lane;
             dm[i] = __ballot(any && a < A && R.nd()[a < A ? a : 0] == tmin);
         }
-        stage_next();
         WSYNC();
-        R.task_update(now, mwt, lane, flags);                                // :570
+        R.task_update(now, mwt, lane, -1, redo, n_infeas);                   // :570
         WSYNC();
         R.agent_update(now, mwt, P.reactive, visible, lane, flags);          // :571
         WSYNC();
@@ -283,11 +313,19 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
                 m &= m - 1;
                 const int len = uni(R.plen()[a]), head = uni(R.phead()[a]);
                 int action;
+                bool popped = false;
+                int32_t upcoming = 0;
                 if (len < 0 || head >= len) action = 0;                      // :573-577
                 else {
-                    const int nxt = my_routes[(size_t)a * route_cap + head];
+                    const int nxt = (int)uni(R.aw()[a]);                     // == my_routes[a][head]
                     if (P.reactive && nxt > visible) action = 0;             // :578-584
-                    else { action = nxt; if (lane == 0) R.phead()[a] = head + 1; }   // :585 pop(0)
+                    else {
+                        action = nxt; popped = true;                         // :585 pop(0)
+                        if (lane == 0) {
+                            R.phead()[a] = head + 1;
+                            if (head + 1 < len) upcoming = my_routes[(size_t)a * route_cap + head + 1];
+                        }
+                    }
                 }
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
                 // agent_step :300-324
@@ -321,9 +359,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, con
                 flags |= (uint32_t)__builtin_amdgcn_readlane((int)flags, 0);
                 if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
                 WSYNC();
-                stage_next();
-                WSYNC();
-                R.task_update(now, mwt, lane, flags);                        // :575/:582/:586
+                R.task_update(now, mwt, lane, redo ? -1 : (action > 0 ? action - 1 : -2), redo, n_infeas);   // :575/:582/:586
+                if (popped && lane == 0) R.aw()[a] = (double)upcoming;       // before agent_update: its reactive branch reads it
                 WSYNC();
                 R.agent_update(now, mwt, P.reactive, visible, lane, flags);  // :576/:583/:587
                 WSYNC();
