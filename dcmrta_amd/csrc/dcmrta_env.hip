@@ -133,11 +133,20 @@ struct Sim {
     // arrivals in registers.  status = requirements - len(members) is the coalition capability-vs-
     // requirement reduction.  Straight-line predicated code; the member-removal compaction is the only
     // (rare) divergent branch.
-    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane) const {
+    //
+    // Incremental mode (shapes with more than one lane pass over the tasks, persistent kernel only): `only` names the task
+    // the deciding agents have just joined (-2: they went to the depot, -1: every task).  At an unchanged `now` a second
+    // call can only change a task whose member list was touched or that became feasible in the previous call (a
+    // Q1-skipped member, the stale status after the spread branch, `finished` of a freshly feasible task :273), so when
+    // the previous call reported neither (inc_state()[1] == 0) all other tasks are at a fixed point and are skipped:
+    // T/64 lane passes become one.  inc_state()[0] carries the number of infeasible tasks for np.all(feasible) :279.
+    static constexpr bool INC = (CT == 0 || CT > WAVE);
+    __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + L().aux() + 8); }
+    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1) const {
         const double now = h.now, mwt = P.mwt;
         const int T_ = T();
-        bool allf = true;
-        for (int t = lane; t < T_; t += WAVE) {
+        bool allf = true, touched = false;
+        auto one = [&](int t) {
             uint32_t info = tinfo()[t];
             const bool feas0 = info & T_FEAS;
             const int req = info & 0xFF;
@@ -204,8 +213,52 @@ struct Sim {
             }
             tinfo()[t] = info;
             allf = allf && (info & T_FEAS);
+            touched = touched || any_drop || (!feas0 && ok);
+        };
+        bool all_feasible;
+        if constexpr (!INC) {
+            for (int t = lane; t < T_; t += WAVE) one(t);
+            all_feasible = __all(allf);
+        } else {
+            int32_t* st = inc_state();
+            const bool full = (only == -1) || (uni(st[1]) != 0);
+            int n_infeas;
+            if (full) {
+                n_infeas = 0;
+                for (int t0 = 0; t0 < T_; t0 += WAVE) {                        // uniform trip count: ballots inside
+                    const int t = t0 + lane;
+                    allf = true;
+                    if (t < T_) one(t);
+                    n_infeas += __popcll(__ballot(!allf));
+                }
+            } else {
+                n_infeas = uni(st[0]);
+#ifdef DCM_INC_DEBUG   // dry run: would a full pass have changed any OTHER task?
+                for (int t0 = 0; t0 < T_; t0 += WAVE) {
+                    const int t = t0 + lane;
+                    if (t < T_ && t != only) {
+                        const uint32_t i0 = tinfo()[t];
+                        const int req = i0 & 0xFF, n = (i0 >> 16) & 0xFF, st0 = (int)(int8_t)((i0 >> 8) & 0xFF);
+                        bool chg = false;
+                        double mx = __builtin_nan(""), mn = __builtin_nan("");
+                        for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * T_ + t]); mn = nanmin2(mn, marr()[j * T_ + t]); }
+                        if (!(i0 & T_FEAS)) {
+                            const int status = req - n;
+                            if (status != st0) chg = true;
+                            if (status <= 0) { if (mx - mn <= mwt) chg = true; else if (mn <= mx - mwt) chg = true; }
+                            else if (now - mn >= mwt) chg = true;
+                        } else if (now >= tf()[t] && !(i0 & T_FIN)) chg = true;
+                        if (chg) printf("INC-DEBUG block %d d %llu task %d only %d info %08x now %.17g mn %.17g mx %.17g tf %.17g redo %d\n", (int)blockIdx.x, (unsigned long long)h.d, t, only, i0, now, mn, mx, tf()[t], (int)st[1]);
+                    }
+                }
+#endif
+                if (only >= 0 && lane == (only & (WAVE - 1))) one(only);
+                n_infeas -= __any(touched && allf) ? 1 : 0;                    // `only` was infeasible (it was joinable) and is feasible now
+            }
+            const int redo = __any(touched) ? 1 : 0;                           // (a ballot inside `if (lane == 0)` would only see lane 0)
+            if (lane == 0) { st[0] = n_infeas; st[1] = redo; }
+            all_feasible = n_infeas == 0;
         }
-        const bool all_feasible = __all(allf);
         WSYNC();
         // depot :277-280
         const int A_ = A();
@@ -603,7 +656,8 @@ struct Sim {
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
                                                       const RouteLog* log = nullptr, int log_row = 0,
-                                                      bool no_grouping = false, bool check_mask = false) const {
+                                                      bool no_grouping = false, bool check_mask = false,
+                                                      bool incremental = false) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         if (check_mask && action > 0) {
@@ -719,7 +773,7 @@ struct Sim {
         h.d += 1;
         WSYNC();
         PH_MARK(3);
-        task_update(h, P, lane);                                              // worker.py:74
+        task_update(h, P, lane, incremental ? (action > 0 ? action - 1 : -2) : -1);   // worker.py:74
         WSYNC();
         PH_MARK(4);
         agent_update(h, P, lane);                                             // worker.py:76
@@ -908,6 +962,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     S.set_ablog(ablog, e, LP.A, lane);
+    if (lane == 0) S.inc_state()[1] = 1;   // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
@@ -953,7 +1008,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
             WSYNC(); S.agent_update(h, P, lane); WSYNC();
 #endif
             PH_MARK(2);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, nullptr, 0, false, false, true);
             gd += GAMMA;
             steps++;
         }
