@@ -221,7 +221,7 @@ struct Sim {
             all_feasible = __all(allf);
         } else {
             int32_t* st = inc_state();
-            const bool full = (only == -1) || (uni(st[1]) != 0);
+            const bool full = (only == -1) || T_ <= WAVE || (uni(st[1]) != 0);   // one lane pass anyway: nothing to skip
             int n_infeas;
             if (full) {
                 n_infeas = 0;
