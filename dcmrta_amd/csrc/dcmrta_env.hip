@@ -140,7 +140,11 @@ struct Sim {
     // Q1-skipped member, the stale status after the spread branch, `finished` of a freshly feasible task :273), so when
     // the previous call reported neither (inc_state()[1] == 0) all other tasks are at a fixed point and are skipped:
     // T/64 lane passes become one.  inc_state()[0] carries the number of infeasible tasks for np.all(feasible) :279.
+#ifdef DCM_NO_INC
+    static constexpr bool INC = false;
+#else
     static constexpr bool INC = (CT == 0 || CT > WAVE);
+#endif
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + L().aux() + 8); }
     __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1) const {
         const double now = h.now, mwt = P.mwt;
@@ -213,7 +217,9 @@ struct Sim {
             }
             tinfo()[t] = info;
             allf = allf && (info & T_FEAS);
-            touched = touched || any_drop || (!feas0 && ok);
+            // a freshly feasible task only changes again at this `now` if it is already over (finished is evaluated one
+            // call later, :273): now >= time_finish needs zero duration and every member already there
+            touched = touched || any_drop || (!feas0 && ok && now >= mx + dur);
         };
         bool all_feasible;
         if constexpr (!INC) {
@@ -252,8 +258,9 @@ struct Sim {
                     }
                 }
 #endif
-                if (only >= 0 && lane == (only & (WAVE - 1))) one(only);
-                n_infeas -= __any(touched && allf) ? 1 : 0;                    // `only` was infeasible (it was joinable) and is feasible now
+                const bool mine = only >= 0 && lane == (only & (WAVE - 1));
+                if (mine) one(only);
+                n_infeas -= __any(mine && allf) ? 1 : 0;   // `only` was infeasible (it was joinable) and is feasible now
             }
             const int redo = __any(touched) ? 1 : 0;                           // (a ballot inside `if (lane == 0)` would only see lane 0)
             if (lane == 0) { st[0] = n_infeas; st[1] = redo; }

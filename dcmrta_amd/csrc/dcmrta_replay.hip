@@ -108,8 +108,9 @@ struct Rep {
                 double mx = marr()[t], mn = mx;
                 for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
                 if (mx - mn <= mwt) {                                        // :255
-                    ts()[t] = mx; tf()[t] = mx + tdur()[t]; info |= T_FEAS;  // :256-258
-                    touched = true;
+                    const double tfin = mx + tdur()[t];
+                    ts()[t] = mx; tf()[t] = tfin; info |= T_FEAS;            // :256-258
+                    touched = now >= tfin;   // only a task that is already over changes again at this `now` (finished, :273)
                 } else {
                     const double thr = mx - mwt;                             // :262
                     for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }

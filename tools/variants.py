@@ -25,7 +25,8 @@ res = {n: [] for n, _ in variants}
 for rnd in range(2):
     for name, so in variants:
         env = dict(os.environ, DCMRTA_HIP_LIB=so)
-        o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+        o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline",
+                            "--no-lockstep-probe"] + os.environ.get("VARIANTS_ARGS", "").split(),
                            env=env, capture_output=True, text=True)
         line = [l for l in o.stdout.splitlines() if l.startswith("{")]
         if not line:
