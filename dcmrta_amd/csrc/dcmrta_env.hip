@@ -227,7 +227,11 @@ struct Sim {
             all_feasible = __all(allf);
         } else {
             int32_t* st = inc_state();
+#ifdef DCM_INC_FORCE_SINGLE   // timing probe only (wrong results): never take the full pass after an agent_step
+            const bool full = (only == -1);
+#else
             const bool full = (only == -1) || T_ <= WAVE || (uni(st[1]) != 0);   // one lane pass anyway: nothing to skip
+#endif
             int n_infeas;
             if (full) {
                 n_infeas = 0;
