@@ -138,8 +138,9 @@ struct Sim {
     // the deciding agents have just joined (-2: they went to the depot, -1: every task).  At an unchanged `now` a second
     // call can only change a task whose member list was touched or that became feasible in the previous call (a
     // Q1-skipped member, the stale status after the spread branch, `finished` of a freshly feasible task :273), so when
-    // the previous call reported neither (inc_state()[1] == 0) all other tasks are at a fixed point and are skipped:
-    // T/64 lane passes become one.  inc_state()[0] carries the number of infeasible tasks for np.all(feasible) :279.
+    // the call only revisits the 64-task lane chunks the previous call touched (bitmask in inc_state()[1]) plus the chunk
+    // of `only`; every other task is at a fixed point of task_update.  inc_state()[0] carries the number of infeasible
+    // tasks for np.all(feasible) :279.
 #ifdef DCM_NO_INC
     static constexpr bool INC = false;
 #else
@@ -226,48 +227,50 @@ struct Sim {
             for (int t = lane; t < T_; t += WAVE) one(t);
             all_feasible = __all(allf);
         } else {
+            // st[0] = number of infeasible tasks, st[1] = lane-chunk bitmask of the tasks the previous call touched
             int32_t* st = inc_state();
-#ifdef DCM_INC_FORCE_SINGLE   // timing probe only (wrong results): never take the full pass after an agent_step
-            const bool full = (only == -1);
+            const uint32_t nchunk = (uint32_t)(T_ + WAVE - 1) / WAVE, all = nchunk >= 32 ? ~0u : ((1u << nchunk) - 1u);
+            uint32_t todo = all;
+            if (only != -1 && T_ > WAVE) {
+#ifdef DCM_INC_FORCE_SINGLE   // timing probe only (wrong results): never revisit what the previous call touched
+                todo = only >= 0 ? (1u << (only >> 6)) : 0u;
 #else
-            const bool full = (only == -1) || T_ <= WAVE || (uni(st[1]) != 0);   // one lane pass anyway: nothing to skip
+                todo = ((uint32_t)uni(st[1]) | (only >= 0 ? (1u << (only >> 6)) : 0u)) & all;
 #endif
-            int n_infeas;
-            if (full) {
-                n_infeas = 0;
-                for (int t0 = 0; t0 < T_; t0 += WAVE) {                        // uniform trip count: ballots inside
-                    const int t = t0 + lane;
-                    allf = true;
-                    if (t < T_) one(t);
-                    n_infeas += __popcll(__ballot(!allf));
-                }
-            } else {
-                n_infeas = uni(st[0]);
-#ifdef DCM_INC_DEBUG   // dry run: would a full pass have changed any OTHER task?
-                for (int t0 = 0; t0 < T_; t0 += WAVE) {
-                    const int t = t0 + lane;
-                    if (t < T_ && t != only) {
-                        const uint32_t i0 = tinfo()[t];
-                        const int req = i0 & 0xFF, n = (i0 >> 16) & 0xFF, st0 = (int)(int8_t)((i0 >> 8) & 0xFF);
-                        bool chg = false;
-                        double mx = __builtin_nan(""), mn = __builtin_nan("");
-                        for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * T_ + t]); mn = nanmin2(mn, marr()[j * T_ + t]); }
-                        if (!(i0 & T_FEAS)) {
-                            const int status = req - n;
-                            if (status != st0) chg = true;
-                            if (status <= 0) { if (mx - mn <= mwt) chg = true; else if (mn <= mx - mwt) chg = true; }
-                            else if (now - mn >= mwt) chg = true;
-                        } else if (now >= tf()[t] && !(i0 & T_FIN)) chg = true;
-                        if (chg) printf("INC-DEBUG block %d d %llu task %d only %d info %08x now %.17g mn %.17g mx %.17g tf %.17g redo %d\n", (int)blockIdx.x, (unsigned long long)h.d, t, only, i0, now, mn, mx, tf()[t], (int)st[1]);
-                    }
-                }
-#endif
-                const bool mine = only >= 0 && lane == (only & (WAVE - 1));
-                if (mine) one(only);
-                n_infeas -= __any(mine && allf) ? 1 : 0;   // `only` was infeasible (it was joinable) and is feasible now
             }
-            const int redo = __any(touched) ? 1 : 0;                           // (a ballot inside `if (lane == 0)` would only see lane 0)
-            if (lane == 0) { st[0] = n_infeas; st[1] = redo; }
+            const bool full = todo == all;
+            int n_infeas = full ? 0 : uni(st[0]);
+            uint32_t dirty = 0;
+#ifdef DCM_INC_DEBUG   // dry run: would a full pass have changed a task outside the chunks about to be processed?
+            for (int t0 = 0; t0 < T_; t0 += WAVE) {
+                const int t = t0 + lane;
+                if (t < T_ && !((todo >> (t0 >> 6)) & 1u)) {
+                    const uint32_t i0 = tinfo()[t];
+                    const int req = i0 & 0xFF, n = (i0 >> 16) & 0xFF, st0 = (int)(int8_t)((i0 >> 8) & 0xFF);
+                    bool chg = false;
+                    double mx = __builtin_nan(""), mn = __builtin_nan("");
+                    for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * T_ + t]); mn = nanmin2(mn, marr()[j * T_ + t]); }
+                    if (!(i0 & T_FEAS)) {
+                        const int status = req - n;
+                        if (status != st0) chg = true;
+                        if (status <= 0) { if (mx - mn <= mwt) chg = true; else if (mn <= mx - mwt) chg = true; }
+                        else if (now - mn >= mwt) chg = true;
+                    } else if (now >= tf()[t] && !(i0 & T_FIN)) chg = true;
+                    if (chg) printf("INC-DEBUG block %d d %llu task %d only %d info %08x now %.17g mn %.17g mx %.17g tf %.17g todo %x\n", (int)blockIdx.x, (unsigned long long)h.d, t, only, i0, now, mn, mx, tf()[t], todo);
+                }
+            }
+#endif
+            for (uint32_t c = 0; c < nchunk; c++) {                            // uniform trip count and branch: ballots inside
+                if (!((todo >> c) & 1u)) continue;
+                const int t = (int)(c * WAVE) + lane;
+                allf = true; touched = false;
+                bool was_infeasible = false;
+                if (t < T_) { was_infeasible = !(tinfo()[t] & T_FEAS); one(t); }
+                if (full) n_infeas += __popcll(__ballot(!allf));
+                else n_infeas -= __popcll(__ballot(was_infeasible && allf));    // became feasible in this call
+                if (__any(touched)) dirty |= 1u << c;
+            }
+            if (lane == 0) { st[0] = n_infeas; st[1] = (int32_t)dirty; }
             all_feasible = n_infeas == 0;
         }
         WSYNC();
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     S.set_ablog(ablog, e, LP.A, lane);
-    if (lane == 0) S.inc_state()[1] = 1;   // incremental task_update: nothing is known about the last call of the previous launch
+    if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
