@@ -489,17 +489,26 @@ struct Sim {
                 int first = -1;
 #pragma unroll
                 for (int i = NAW - 1; i >= 0; i--) if (dm[i]) first = i * 64 + __ffsll((unsigned long long)dm[i]) - 1;
-                // fast path: every deciding agent stands on the same point -> one group
-                const double x0 = ax()[first], y0 = ay()[first];
+                // fast paths: a single deciding agent, or every deciding agent on the same point -> one group
+                int ndec = 0;
+#pragma unroll
+                for (int i = 0; i < NAW; i++) ndec += __popcll(dm[i]);
                 bool same = true;
                 double px[NAW], py[NAW];
+#ifndef DCM_NO_SINGLE_DECIDER
+                if (ndec > 1 && !no_grouping)
+#endif
+                {
+                    const double x0 = ax()[first], y0 = ay()[first];
 #pragma unroll
-                for (int i = 0; i < NAW; i++) {
-                    const int a = i * 64 + lane;
-                    px[i] = ax()[a < A_ ? a : 0]; py[i] = ay()[a < A_ ? a : 0];
-                    same = same && (!dec[i] || (px[i] == x0 && py[i] == y0));
+                    for (int i = 0; i < NAW; i++) {
+                        const int a = i * 64 + lane;
+                        px[i] = ax()[a < A_ ? a : 0]; py[i] = ay()[a < A_ ? a : 0];
+                        same = same && (!dec[i] || (px[i] == x0 && py[i] == y0));
+                    }
+                    same = __all(same);
                 }
-                if (no_grouping || __all(same)) {
+                if (no_grouping || same) {
 #pragma unroll
                     for (int i = 0; i < NAW; i++) {
                         const int a = i * 64 + lane;
