@@ -274,11 +274,13 @@ struct Sim {
             all_feasible = n_infeas == 0;
         }
         WSYNC();
-        // depot :277-280
-        const int A_ = A();
-        for (int a = lane; a < A_; a += WAVE) {
-            const uint32_t ai = ainfo()[a];
-            if ((ai & A_INDEPOT) && all_feasible && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+        // depot :277-280 (np.all(feasible) is wave-uniform and false until the last task is feasible: nothing to scan before)
+        if (all_feasible) {
+            const int A_ = A();
+            for (int a = lane; a < A_; a += WAVE) {
+                const uint32_t ai = ainfo()[a];
+                if ((ai & A_INDEPOT) && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+            }
         }
     }
 
@@ -712,6 +714,7 @@ struct Sim {
             const int k = action - 1;
             int nf;
             if (nfol_in >= 0) nf = nfol_in;                                   // injected (also for the depot: individual selection)
+            else if (rlen == 0) nf = 0;                                       // nobody left to follow: min(vacancy - 1, 0)
             else {
                 const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
                 nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331

@@ -176,9 +176,11 @@ struct Rep {
         redo = __any(touched);
         const bool all_feasible = n_infeas == 0;
         WSYNC();
-        for (int a = lane; a < A; a += WAVE) {                               // depot :277-280
-            const uint32_t ai = ainfo()[a];
-            if ((ai & A_INDEPOT) && all_feasible && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+        if (all_feasible) {                                                  // depot :277-280 (uniform; false until the very end)
+            for (int a = lane; a < A; a += WAVE) {
+                const uint32_t ai = ainfo()[a];
+                if ((ai & A_INDEPOT) && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
+            }
         }
     }
 
