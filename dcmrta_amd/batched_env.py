@@ -219,6 +219,13 @@ class BatchedTaskEnv:
             check(self._lib.dcm_get_agents(self._h, *[_ptr(v) for v in o.values()], self._stream()))
         return o
 
+    def task_members(self):
+        """int16[B,T,5]: task['members'] of every task in list order, -1 padded (env/task_env.py:80)."""
+        out = torch.empty((self.B, self.T, _lib.MAX_MEMBERS), dtype=torch.int16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_get_members(self._h, _ptr(out), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ route history (agent['route'], agent['arrival_time'])
     def enable_route_log(self, cap=64):
         """Record every agent_step of the lockstep API (reset / step): route_task[B,A,cap] (-1 = depot), route_arrival, route_len."""

@@ -1123,6 +1123,24 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigne
     }
 }
 
+// task['members'] of every task, in list order (env/task_env.py:80): ids_out[B][T][DCM_MAX_MEMBERS], -1 padded
+__global__ void k_get_members(int A, int T, const unsigned char* state, int B, int16_t* ids_out, const int32_t* sizes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int e = (int)(i / T), t = (int)(i % T);
+    int eA = A, eT = T;
+    if (sizes) { eA = sizes[2 * e]; eT = sizes[2 * e + 1]; }
+    const Lay L{eA, eT};
+    const unsigned char* rec = state + (size_t)e * Lay{A, T}.rec_bytes();
+    uint64_t ids = 0;
+    int n = 0;
+    if (t < eT) {
+        ids = ((const uint64_t*)(rec + L.mids()))[t];
+        n = (int)((((const uint32_t*)(rec + L.tinfo()))[t] >> 16) & 0xFF);
+    }
+    for (int j = 0; j < M; j++) ids_out[i * M + j] = (j < n) ? (int16_t)((ids >> (8 * j)) & 0xFF) : (int16_t)-1;
+}
+
 __global__ void k_distance(const double* ax, const double* ay, const double* bx, const double* by, double* dist_out,
                            double* time_out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1378,6 +1396,16 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
     hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
                        pending_group, env->ablog, (const int32_t*)env->sizes);
+    LAUNCH_OK();
+    return DCM_OK;
+}
+
+int dcm_get_members(dcm_env* env, int16_t* ids_out, void* stream) {
+    CHECK_ENV(env);
+    if (!ids_out) return fail(DCM_ERR_INVALID, "dcm_get_members: null ids_out");
+    const int64_t n = (int64_t)env->p.n_envs * env->L.T;
+    hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->L.A, env->L.T,
+                       env->state, env->p.n_envs, ids_out, (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
 }

@@ -171,6 +171,10 @@ int dcm_get_agents(dcm_env *env, double *sum_wait, double *travel_dist, double *
                    double *x, double *y, uint8_t *returned, uint8_t *assigned, int32_t *current,
                    int32_t *pending_group, void *stream);
 
+/* task['members'] (env/task_env.py:80) of every task in list order: ids_out int16[B,T,DCM_MAX_MEMBERS], -1 padded
+ * (what generate_traj :390,:400 and the plotting code test membership against). */
+int dcm_get_members(dcm_env *env, int16_t *ids_out, void *stream);
+
 /* copy.deepcopy(env) (worker.py:33): snapshot / restore of the mutable SoA state.
  * dcm_state_bytes gives the buffer size (device memory) needed for all B envs. */
 int dcm_state_bytes(dcm_env *env, size_t *bytes_out);

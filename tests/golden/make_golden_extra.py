@@ -142,7 +142,41 @@ def random_replays():
         json.dump(cases, f, separators=(",", ":"))
 
 
+def trajectory_goldens():
+    """generate_traj (env/task_env.py:375-418) of the reference after one harness episode: the sampled positions of every
+    agent plus everything a pure re-implementation needs as input (routes, arrivals, final member lists, task times)."""
+    out = {}
+    for (A, T, pol, s) in ((5, 8, "random", 3), (10, 20, "nearest", 4), (6, 9, "random", 5)):
+        env = TaskEnv((A, A), (T, T), 1, 5, seed=s)
+        se = mg.env_seed(5600, s)
+        tr = run(env, se, pol)
+        env.generate_traj()
+        ia = mg.instance_arrays(env)
+        rl = max(len(a["route"]) for a in env.agent_dic.values())
+        route = np.full((A, rl), -2, np.int32)
+        arrival = np.zeros((A, rl))
+        for a, ag in env.agent_dic.items():
+            route[a, :len(ag["route"])] = ag["route"]
+            arrival[a, :len(ag["arrival_time"])] = ag["arrival_time"]
+        members = np.full((T, 5), -1, np.int16)
+        for t, tk in env.task_dic.items():
+            members[t, :len(tk["members"])] = tk["members"]
+        traj = [np.array(ag["trajectory"], np.float64).reshape(-1, 3) for ag in env.agent_dic.values()]
+        tl = np.array([len(x) for x in traj], np.int32)
+        flat = np.concatenate(traj) if tl.sum() else np.zeros((0, 3))
+        key = f"traj_{A}A{T}T_{pol}_s{s}"
+        np.savez_compressed(os.path.join(HERE, key + ".npz"), seed_e=np.uint64(se), inst_seed=np.int64(s), depot=ia["depot"],
+                            task_xy=ia["task_xy"], req=ia["req"], dur=ia["dur"], route=route, arrival=arrival, members=members,
+                            feasible=tr["feasible"], time_start=tr["time_start"], time_finish=tr["time_finish"],
+                            current_time=np.float64(env.current_time), action=tr["action"], traj=flat, traj_len=tl)
+        print(key, int(tr["n_steps"]), tl.tolist(), flush=True)
+
+
 def main():
+    if "--only-traj" in sys.argv:
+        trajectory_goldens()
+        return
+    trajectory_goldens()
     if "--skip-replays" not in sys.argv:
         random_replays()
     out = {}

@@ -39,3 +39,22 @@ def test_route_log_equals_oracle_routes(gpu_device, oracle_lib, golden_dir, tmp_
     # a second reset clears the log
     env.reset(seeds, observe=False)
     assert int(env.routes()[2].sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["traj_5A8T_random_s3.npz", "traj_10A20T_nearest_s4.npz", "traj_6A9T_random_s5.npz"])
+def test_generate_traj_from_device_state(gpu_device, golden_dir, name):
+    """generate_traj (env/task_env.py:375-418) from the device state alone -- route log, dcm_get_members, task times --
+    equals the trajectories the reference produced for the same episode (recorded actions, protocol leaders/followers)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.trajectory import generate_traj
+    from test_host import _traj_fixture
+    z, routes, members, ref = _traj_fixture(golden_dir, name)
+    A, T = z["route"].shape[0], z["task_xy"].shape[0]
+    env = BatchedTaskEnv(1, A, T, device=gpu_device).enable_route_log(cap=64)
+    env.load_instances(z["depot"][None], z["task_xy"][None], z["req"][None], z["dur"][None])
+    H.run_lockstep(env, np.array([int(z["seed_e"])], np.uint64), lambda b, i, m, l: int(z["action"][i]))
+    mem = env.task_members()[0].cpu().numpy()
+    assert np.array_equal(mem, z["members"])                                   # final task['members'] lists, in order
+    got = generate_traj(env, 0)
+    for a, (g, r) in enumerate(zip(got, ref)):
+        assert g.shape == r.shape and np.array_equal(g, r), (name, a)

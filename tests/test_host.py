@@ -138,3 +138,29 @@ def test_ragged_batch_generator_matches_reference_sizes(golden_dir):
         assert (a, t) == (r["A"], r["T"]) and inst["depot"][b].tolist() == r["depot"]
         assert inst["req"][b, :t].tolist() == r["req"] and inst["task_xy"][b, t - 1].tolist() == r["task_xy_last"]
         assert (inst["req"][b, t:] == 1).all() and not inst["task_xy"][b, t:].any() and (inst["dur"][b, :t] == 5.0).all()
+
+
+def _traj_fixture(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    A = z["route"].shape[0]
+    routes = []
+    for a in range(A):
+        n = int((z["route"][a] != -2).sum())
+        routes.append(([int(x) for x in z["route"][a, :n]], [float(x) for x in z["arrival"][a, :n]]))
+    members = [[int(x) for x in row if x >= 0] for row in z["members"]]
+    ends = np.cumsum(z["traj_len"])
+    ref = [z["traj"][e - n:e] for e, n in zip(ends, z["traj_len"])]
+    return z, routes, members, ref
+
+
+@pytest.mark.parametrize("name", ["traj_5A8T_random_s3.npz", "traj_10A20T_nearest_s4.npz", "traj_6A9T_random_s5.npz"])
+def test_generate_traj_matches_reference(golden_dir, name):
+    """trajectory.trajectories restates generate_traj (env/task_env.py:375-418): sampled (x, y, heading) of every agent,
+    bit for bit, from the reference's own routes / member lists / task times (tests/golden/make_golden_extra.py)."""
+    from dcmrta_amd.trajectory import trajectories
+    z, routes, members, ref = _traj_fixture(golden_dir, name)
+    got = trajectories(routes, z["depot"], z["task_xy"], members, z["feasible"].astype(bool), z["time_start"], z["time_finish"],
+                       float(z["current_time"]))
+    assert len(got) == len(ref)
+    for a, (g, r) in enumerate(zip(got, ref)):
+        assert g.shape == r.shape and np.array_equal(g, r), (name, a)
