@@ -63,6 +63,8 @@ class TaskEnv:
                                    individual_selection=individual_selection)
         self._env.load_instances(depot[None], task_xy[None], req[None], dur[None])
         self._seed = np.array([choice_seed], dtype=np.uint64)
+        self._preset = [None] * A                      # agent['pre_set_route'], :595-599
+        self._replay_summary = None
         self.depot = {"location": depot.copy(), "members": [], "ID": -1}
         self.clear_decisions()
 
@@ -75,6 +77,8 @@ class TaskEnv:
         self.clear_decisions()
 
     def clear_decisions(self):
+        self._preset = [None] * self.agents_num
+        self._replay_summary = None
         self._env.reset(self._seed, observe=False)
         self.finished = False
         self._visible_time = 0.0
@@ -226,9 +230,44 @@ class TaskEnv:
 
     def perf_metrics(self):
         """worker.py:103-108."""
-        sm = self._env.summary()[0].cpu().numpy()
+        sm = self._replay_summary if self._replay_summary is not None else self._env.summary()[0].cpu().numpy()
         return dict(success_rate=sm[2], makespan=sm[3], time_cost=sm[4], waiting_time=sm[5], travel_dist=sm[6],
                     efficiency=sm[7])
 
+    # ------------------------------------------------------------------ route replay (env/task_env.py:562-599)
     def pre_set_route(self, routes, agent_id):
-        raise NotImplementedError("route replay runs through BatchedTaskEnv.execute_routes")
+        """:595-599: set, or extend, the preset action list of one agent (0 = depot, k = task k-1)."""
+        cur = self._preset[agent_id]
+        self._preset[agent_id] = list(routes) if not cur else cur + list(routes)
+
+    def execute_by_route(self, path="./", method=0, plot_figure=False):
+        """:562-593 on the device (dcm_load_routes + dcm_execute_routes; max_waiting_time 100, cut-off 200, dynamic task
+        visibility when `reactive_planning` is set).  Afterwards current_time, get_episode_reward, task_dic / agent_dic
+        (finished, time_start, time_finish, sum_waiting_time, travel_dist, returned) describe the replayed episode, as
+        baselines/CTAS-D.py:83-94 reads them.  Raises TypeError where the reference does (:220, pre_set_route None)."""
+        self._env.load_routes([self._preset], member_cap=min(32, max(8, self.agents_num)))
+        out = self._env.execute_routes(reactive=bool(self.reactive_planning))
+        flags = int(out["flags"][0])
+        if flags & _lib.FLAG_TYPE_ERROR:
+            raise TypeError("'NoneType' object is not subscriptable")       # the reference's own failure, :220
+        if flags & (_lib.FLAG_OVERFLOW | _lib.FLAG_BAD_ACTION):
+            raise RuntimeError(f"route replay error flags {flags:#x} (more visitors on one task than member_cap, or a bad action id)")
+        if flags & _lib.FLAG_TRUNCATED:
+            raise RuntimeError("the reference never terminates on these routes (every agent idle while tasks stay open)")
+        g = lambda k: out[k][0].cpu().numpy()
+        sm = out["summary"][0].cpu().numpy()
+        A, T = self.agents_num, self.tasks_num
+        nanA, zerA = np.full(A, np.nan), np.zeros(A)
+        self._ag = dict(x=nanA, y=nanA, returned=g("returned"), assigned=zerA, next_decision=nanA, arrival=nanA,
+                        travel_dist=g("travel_dist"), sum_waiting_time=g("agent_wait"), current=np.full(A, -1), pending_group=zerA)
+        fin = g("finished")
+        self._tk = dict(feasible=fin.copy(), finished=fin, time_start=g("time_start"), time_finish=g("time_finish"),
+                        status=np.zeros(T, np.int32), sum_waiting_time=g("task_wait"), n_members=g("n_members"),
+                        n_abandoned=np.zeros(T, np.int32))
+        self._now = float(sm[3])
+        self._flags = flags | _lib.FLAG_DONE
+        self._replay_summary = sm
+        self._dirty = False
+        self.finished = bool(flags & _lib.FLAG_FINISHED)
+        self.max_waiting_time = 100.0                                        # :564
+        return self._now
