@@ -55,6 +55,7 @@ class TaskEnv:
     def _init_from_arrays(self, A, depot, task_xy, req, dur, device, choice_seed, max_waiting_time=10.0,
                           individual_selection=False):
         self.agents_num, self.tasks_num = A, len(req)
+        self._individual_selection = bool(individual_selection)
         self.max_waiting_time = float(max_waiting_time)
         self.reactive_planning = False
         self.dt = 0.1
@@ -70,10 +71,24 @@ class TaskEnv:
 
     # ------------------------------------------------------------------ reset (env/task_env.py:116-140)
     def reset(self, test_env=None, seed=None):
-        if test_env is not None:
-            raise NotImplementedError("swap instances with TaskEnv.from_arrays(...)")
+        """:116-127.  test_env = (task_dic, agent_dic, depot) in the reference's dict layout (what RL_test.py:36-42 and
+        baselines/CTAS-D.py:60-66 pass after unpickling a test-set env): the instance is read out of the dicts
+        (location / requirements / time per task, the agent count, the depot location) and loaded onto the device."""
         if seed is not None:
             self._seed = np.array([seed], dtype=np.uint64)
+        if test_env is not None:
+            task_dic, agent_dic, depot = test_env
+            T = len(task_dic)
+            first = lambda x: np.asarray(x, dtype=np.float64).reshape(-1)[0]
+            xy = np.stack([np.asarray(task_dic[i]["location"], dtype=np.float64).reshape(-1)[:2] for i in range(T)])
+            req = np.array([int(first(task_dic[i]["requirements"])) for i in range(T)], np.int32)
+            dur = np.array([first(task_dic[i]["time"]) for i in range(T)], np.float64)
+            dep = np.asarray(depot["location"], dtype=np.float64).reshape(-1)[:2]
+            old = self._env
+            self._init_from_arrays(len(agent_dic), dep, xy, req, dur, str(old.device), int(self._seed[0]), self.max_waiting_time,
+                                   self._individual_selection)
+            old.close()
+            return
         self.clear_decisions()
 
     def clear_decisions(self):

@@ -130,3 +130,38 @@ def test_ctasd_baseline_loop_on_facade(gpu_device, golden_dir):
             env.pre_set_route(copy.copy(r)[1:], a)
     with pytest.raises(TypeError):
         env.execute_by_route("./", "CTAS-D", False)
+
+
+def test_reset_with_reference_dicts(gpu_device, golden_dir):
+    """env.reset((task_dic, agent_dic, depot)) with dicts laid out like the reference's (env/task_env.py:76-113), as
+    RL_test.py:36-42 does after unpickling: the instance is swapped in and the episode equals the one of from_arrays."""
+    from dcmrta_amd.instances import load_instances_npz
+    from dcmrta_amd.task_env import TaskEnv
+    inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    i = 3
+    task_dic = {t: {"ID": t, "requirements": np.array([inst["req"][i][t]]), "members": [], "location": inst["task_xy"][i][t].copy(),
+                    "time": np.array([inst["dur"][i][t]]), "status": np.array([inst["req"][i][t]])} for t in range(50)}
+    agent_dic = {a: {"ID": a, "location": inst["depot"][i].copy(), "route": []} for a in range(A)}
+    depot = {"location": inst["depot"][i].copy(), "members": [], "ID": -1}
+
+    def episode(env):
+        n = 0
+        while not env.finished and env.current_time < 100:
+            ids, t = env.next_decision()
+            groups = env.get_unique_group(ids)
+            env.current_time = t
+            for group in groups:
+                while group:
+                    leader = group[0]
+                    m = env.get_unfinished_task_mask()
+                    action = int(np.flatnonzero(~m)[0]) + 1 if not m.all() else 0
+                    group, _ = env.step(group, leader, action, n)
+                    n += 1
+            env.finished = env.check_finished()
+        return n, env.get_episode_reward(100)[0]
+
+    a = TaskEnv((5, 5), (7, 7), 1, 5, seed=1, device=gpu_device)           # some other instance first
+    a.reset((task_dic, agent_dic, depot))
+    assert (a.agents_num, a.tasks_num) == (A, 50) and np.array_equal(a.depot["location"], inst["depot"][i])
+    b = TaskEnv.from_arrays(A, inst["depot"][i], inst["task_xy"][i], inst["req"][i], inst["dur"][i], device=gpu_device)
+    assert episode(a) == episode(b)
