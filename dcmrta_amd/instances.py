@@ -73,6 +73,27 @@ def generate_batch_ranges(seeds, agents_range, tasks_range, max_coalition_size=5
     return out
 
 
+def instance_from_dicts(task_dic, agent_dic, depot):
+    """(A, instance dict) from the reference's own containers (env/task_env.py:76-113): what `env.reset(test_env)` of
+    RL_test.py:36-42 / baselines/CTAS-D.py:60-66 receives after unpickling a test-set env."""
+    T = len(task_dic)
+    first = lambda x: np.asarray(x, dtype=np.float64).reshape(-1)[0]
+    return len(agent_dic), dict(
+        depot=np.asarray(depot["location"], dtype=np.float64).reshape(-1)[:2].copy(),
+        task_xy=np.stack([np.asarray(task_dic[i]["location"], dtype=np.float64).reshape(-1)[:2] for i in range(T)]),
+        req=np.array([int(first(task_dic[i]["requirements"])) for i in range(T)], np.int32),
+        dur=np.array([first(task_dic[i]["time"]) for i in range(T)], np.float64))
+
+
+def batch_from_dicts(test_envs):
+    """Stack several (task_dic, agent_dic, depot) triples of equal sizes into the load_instances keyword dict; returns (A, dict)."""
+    parts = [instance_from_dicts(*te) for te in test_envs]
+    A = parts[0][0]
+    if any(a != A or p["req"].shape != parts[0][1]["req"].shape for a, p in parts):
+        raise ValueError("all instances of a uniform batch need the same agent and task counts (use n_agents / n_tasks for ragged batches)")
+    return A, {k: np.stack([p[k] for _, p in parts]) for k in ("depot", "task_xy", "req", "dur")}
+
+
 def load_instances_npz(path):
     """Fixture format of tests/golden/instances_20A50T.npz (depot[N,2], task_xy[N,T,2], req[N,T], dur[N,T], A)."""
     z = np.load(path)

@@ -77,15 +77,11 @@ class TaskEnv:
         if seed is not None:
             self._seed = np.array([seed], dtype=np.uint64)
         if test_env is not None:
-            task_dic, agent_dic, depot = test_env
-            T = len(task_dic)
-            first = lambda x: np.asarray(x, dtype=np.float64).reshape(-1)[0]
-            xy = np.stack([np.asarray(task_dic[i]["location"], dtype=np.float64).reshape(-1)[:2] for i in range(T)])
-            req = np.array([int(first(task_dic[i]["requirements"])) for i in range(T)], np.int32)
-            dur = np.array([first(task_dic[i]["time"]) for i in range(T)], np.float64)
-            dep = np.asarray(depot["location"], dtype=np.float64).reshape(-1)[:2]
+            from .instances import instance_from_dicts
+            A, inst = instance_from_dicts(*test_env)
+            dep, xy, req, dur = inst["depot"], inst["task_xy"], inst["req"], inst["dur"]
             old = self._env
-            self._init_from_arrays(len(agent_dic), dep, xy, req, dur, str(old.device), int(self._seed[0]), self.max_waiting_time,
+            self._init_from_arrays(A, dep, xy, req, dur, str(old.device), int(self._seed[0]), self.max_waiting_time,
                                    self._individual_selection)
             old.close()
             return

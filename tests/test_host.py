@@ -164,3 +164,17 @@ def test_generate_traj_matches_reference(golden_dir, name):
     assert len(got) == len(ref)
     for a, (g, r) in enumerate(zip(got, ref)):
         assert g.shape == r.shape and np.array_equal(g, r), (name, a)
+
+
+def test_instances_from_reference_dicts(golden_dir):
+    """instance_from_dicts / batch_from_dicts read the reference's task_dic / agent_dic / depot layout (env/task_env.py:76-113)."""
+    from dcmrta_amd.instances import batch_from_dicts, instance_from_dicts, load_instances_npz
+    inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+
+    def dicts(i):
+        return ({t: {"ID": t, "requirements": np.array([inst["req"][i][t]]), "location": inst["task_xy"][i][t], "time": np.array([inst["dur"][i][t]])}
+                 for t in range(50)}, {a: {"ID": a} for a in range(A)}, {"location": inst["depot"][i], "ID": -1})
+    a, one = instance_from_dicts(*dicts(2))
+    assert a == A and all(np.array_equal(one[k], inst[k][2]) for k in ("depot", "task_xy", "req", "dur"))
+    a, many = batch_from_dicts([dicts(i) for i in (0, 4, 9)])
+    assert a == A and all(np.array_equal(many[k], inst[k][[0, 4, 9]]) for k in ("depot", "task_xy", "req", "dur"))
