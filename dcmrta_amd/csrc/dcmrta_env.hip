@@ -587,7 +587,9 @@ struct Sim {
     // worker.py:54 -- the deciding agent of the current group (protocol slot 0), or the injected one
     // (Keeping the group bitmask in SGPRs from one decision to the next was measured SLOWER: +12 % launch time from
     // the extra SGPR pressure / spills, so it is recomputed with one LDS read + ballot per decision.)
-    __device__ __forceinline__ int pick_leader(Hdr& h, int lane, int leader_in, uint64_t k1, AMask& gm) const {
+    // lowest: individual selection (DCM_PARAM_NO_GROUPING) -- the deciders act one by one in ascending id, `for agent_id in
+    // decision_agents` of worker.py:170, so the next one is simply the lowest pending id (no draw)
+    __device__ __forceinline__ int pick_leader(Hdr& h, int lane, int leader_in, uint64_t k1, AMask& gm, bool lowest = false) const {
         gm = group_mask(h.cur_group, lane);
         const int glen = am_count(gm);
         if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }  // unreachable: groups are never empty
@@ -595,6 +597,7 @@ struct Sim {
             if (leader_in >= A() || !am_test(gm, leader_in)) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }
             return leader_in;
         }
+        if (lowest) return am_nth(gm, 0, lane);
         return am_nth(gm, below((uint32_t)(k1 >> 32), glen), lane);
     }
 
@@ -703,7 +706,7 @@ struct Sim {
         uint64_t mlist = (uint64_t)(uint32_t)leader;                          // ordered member ids, byte j (task actions only)
         int nm = 1;
         double tx_, ty_;
-        if (action == 0 && nfol_in < 0) {
+        if (action == 0 && nfol_in < 0 && !no_grouping) {   // (individual selection: agent_step(agent, 0) moves that agent only)
             // vacancy = len(group) (:327): every co-located agent returns with the leader (Q9); the draw
             // order of the followers cannot change any state, so no draws are spent.
 #pragma unroll
@@ -714,7 +717,7 @@ struct Sim {
             const int k = action - 1;
             int nf;
             if (nfol_in >= 0) nf = nfol_in;                                   // injected (also for the depot: individual selection)
-            else if (rlen == 0) nf = 0;                                       // nobody left to follow: min(vacancy - 1, 0)
+            else if (rlen == 0 || no_grouping) nf = 0;                        // nobody left to follow / individual selection: agent_step alone (worker.py:186)
             else {
                 const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
                 nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
 template <int CA, int CT>
 __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
-                                                 const int32_t* leader_in, const int32_t* sizes) {
+                                                 const int32_t* leader_in, const int32_t* sizes, uint32_t mode) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT>(sizes, e, A, T, eA, eT);
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* s
     const uint32_t flags0 = h.flags;
     if (!(h.flags & DCM_FLAG_DONE)) {
         typename Sim<CA, CT>::AMask gm;
-        leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm);
+        leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
     }
     if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
     else S.write_inactive_obs(lane, ag, tk, mk);
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
     if (was_active) {
         AMask gm;
         const uint64_t k1 = key1(h.seed, h.d);
-        const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm);
+        const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
         if (leader >= 0) {
             const int nf = nfol_in ? nfol_in[e] : -1;
             PH_DECL;
@@ -956,7 +959,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
         float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
         uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
         int leader = -1;
-        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm); }
+        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0); }
         if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
         else S.write_inactive_obs(lane, ag, tk, mk);
         if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
@@ -1312,7 +1315,7 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
 #define CALL(CA, CT)                                                                                                    \
     hipLaunchKernelGGL((k_observe<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,     \
                        env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
-                       (const int32_t*)env->sizes)
+                       (const int32_t*)env->sizes, env->p.flags)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();

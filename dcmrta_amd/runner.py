@@ -155,6 +155,36 @@ class BatchedRunner:
         self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps)
         return jobResults, metrics, info
 
+    # ------------------------------------------------------------------ Worker.run_test / run_test_IS (worker.py:114-198)
+    @torch.no_grad()
+    def run_test(self, instances, n_agents=None, individual_selection=False, seeds=None):
+        """Greedy evaluation of the local network on given instances, as RL_test.py:36-51 does one env at a time.
+
+        instances: the load_instances keyword dict (depot[N,2], task_xy[N,T,2], req[N,T], dur[N,T], optionally n_agents /
+        n_tasks for a ragged set) -- e.g. instances.load_instances_npz or instances.batch_from_dicts of unpickled test-set
+        envs.  Action = argmax(logp.exp() * ~mask) (worker.py:140,185).  individual_selection=True is run_test_IS: the
+        deciders of an event act one by one in ascending id without grouping.  Returns {metric: float64[N]} with the
+        six keys of worker.py:146-151 plus "reward"."""
+        N, T = instances["req"].shape
+        A = int(n_agents if n_agents is not None else (instances["n_agents"].max() if "n_agents" in instances else self._env.A))
+        ss = env_seeds(self.base_seed, 0, N) if seeds is None else np.asarray(seeds, dtype=np.uint64)
+        env = BatchedTaskEnv(N, A, T, device=str(self.device), individual_selection=individual_selection)
+        env.load_instances(**instances)
+        obs = env.reset(ss)
+        for _ in range(self.max_steps * 4):
+            if not bool(obs.active.any()):
+                break
+            logp = self.localNetwork(obs.tasks, obs.agents, obs.mask)
+            action = torch.argmax(logp.exp() * ~obs.mask, dim=1)            # worker.py:140 / :185
+            obs = env.step(action.to(torch.int32))
+        else:
+            raise RuntimeError("run_test did not terminate")
+        sm = env.summary().cpu().numpy()
+        env.close()
+        out = {k: sm[:, 2 + i].copy() for i, k in enumerate(METRIC_KEYS)}
+        out["reward"] = sm[:, 0].copy()
+        return out
+
     # ------------------------------------------------------------------ runner.py:45-49 (greedy evaluation)
     def testing(self, agents_range=(10, 20), tasks_range=(20, 50), seed=None, seeds=None):
         """Greedy reward(s) of the local network on seeded instances; seed -> float, seeds -> numpy array.

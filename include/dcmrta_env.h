@@ -64,9 +64,10 @@ typedef enum {
                                   * i.e. waiting_time may differ from the reference in the last bits */
 #define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 
-/* dcm_params.flags: individual selection -- all agents deciding at an event form ONE group in ascending id order and are
- * meant to be stepped one by one with nfol_in = 0 (Worker.run_test_IS, worker.py:159-198, skips get_unique_group).
- * Honoured by dcm_reset / dcm_step; dcm_rollout_random always groups by location. */
+/* dcm_params.flags: individual selection (Worker.run_test_IS, worker.py:159-198, skips get_unique_group) -- all agents
+ * deciding at an event form ONE group and act one by one in ascending id, each alone: unless a leader / follower count is
+ * injected, dcm_observe / dcm_step take the lowest pending id as the deciding agent and no followers.
+ * Honoured by dcm_reset / dcm_observe / dcm_step; dcm_rollout_random always groups by location. */
 #define DCM_PARAM_NO_GROUPING 1u
 
 typedef struct {

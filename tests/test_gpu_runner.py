@@ -1,5 +1,7 @@
 """-m gpu: BatchedRunner.job keeps the reference runner's contract (runner.py:58-71, driver.py:135-176) and its
 experience replays bit-exactly through the oracle (same choices -> same observations)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,3 +121,45 @@ def test_ragged_job_and_testing(gpu_device, oracle_lib):
     assert rewards.shape == (6,) and (rewards < 0).all()
     assert np.array_equal(rewards, r.testing(AR, TR, seeds=range(40, 46)))
     assert r.testing(AR, TR, seed=43) == rewards[3]
+
+
+def test_run_test_and_run_test_is(gpu_device, oracle_lib, golden_dir):
+    """BatchedRunner.run_test: Worker.run_test (worker.py:114-157) and run_test_IS (:159-198) over the shipped test-set
+    instances in one batch.  The individual-selection run needs no injected choices (the device takes the lowest pending id,
+    no followers) and equals the reference loop restated on the oracle with the same greedy policy decisions."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import load_instances_npz
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import METRIC_KEYS, BatchedRunner
+    torch.manual_seed(7)
+    inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    sub = {k: v[:6] for k, v in inst.items()}
+    r = BatchedRunner(n_envs=6, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32))
+    for is_mode in (False, True):
+        m = r.run_test(sub, n_agents=A, individual_selection=is_mode)
+        assert set(m) == set(METRIC_KEYS) | {"reward"} and all(v.shape == (6,) for v in m.values())
+        assert np.array_equal(m["reward"], -m["makespan"]) and (m["success_rate"] <= 1).all()
+        again = r.run_test(sub, n_agents=A, individual_selection=is_mode)
+        assert all(np.array_equal(m[k], again[k], equal_nan=True) for k in m)
+    # individual selection, stepwise against the oracle: same decisions -> same final state
+    env = BatchedTaskEnv(1, A, 50, device=gpu_device, individual_selection=True)
+    env.load_instances(**{k: v[:1] for k, v in sub.items()})
+    obs = env.reset(np.array([5], np.uint64))
+    o = oracle_lib.OracleEnv(A, 50).load(sub["depot"][0], sub["task_xy"][0], sub["req"][0], sub["dur"][0])
+    n, finished = 0, False
+    while not finished and o.now < 100:                                       # worker.py:163
+        ids, t = o.next_decision()
+        o.now = t
+        o.task_update(); o.agent_update()
+        for a in ids:                                                        # :170 ascending ids, each alone
+            assert bool(obs.active[0]) and int(obs.leader[0]) == int(a)      # the device offers the same agent
+            assert np.array_equal(obs.mask[0, 1:].cpu().numpy().astype(np.uint8), o.mask()[1:])
+            action = int(torch.argmax((~obs.mask[0]).to(torch.int32)))       # first valid action
+            o.agent_step(int(a), action)
+            o.task_update(); o.agent_update()
+            obs = env.step(torch.tensor([action], dtype=torch.int32))
+            n += 1
+        finished = o.check_finished()
+    oracle_lib.lib().orc_finish_episode(o._h)
+    assert not bool(obs.active[0]) and n > 20
+    assert env.summary()[0, 0].item() == o.final()["reward"]
