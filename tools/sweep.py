@@ -24,6 +24,7 @@ TASK_KEYS = ("finished", "feasible", "time_start", "time_finish", "task_wait", "
 AGENT_KEYS = ("travel_dist", "returned", "agent_wait")
 bad, checked, t0 = 0, 0, time.time()
 wait_order = 0
+is_cnt = 0
 for it in range(n_shapes):
     A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
     T = int(rng.choice([1, 2, 7, 20, 37, 50, 63, 64, 65, 100, 128, 129, 200, 300]))
@@ -101,4 +102,42 @@ for it in range(n_shapes):
                 print("MISMATCH", mode, A, T, mwt, base, b, str(ex)[:200], flush=True)
             checked += 1
         env.close()
-print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {time.time() - t0:.0f} s")
+    # individual selection (Worker.run_test_IS, worker.py:159-198): the device offers the lowest pending id and moves it alone;
+    # the reference loop is restated on the oracle's step-wise surface with the same keyed valid-action choice
+    if it % 9 == 4 and A <= 40 and T <= 70 and not ragged:
+        nB = min(B, 4)
+        env = BatchedTaskEnv(nB, A, T, max_waiting_time=mwt, max_time=max_time, individual_selection=True)
+        env.load_instances(**{k: v[:nB] for k, v in inst.items()})
+        got = H.run_lockstep(env, seeds[:nB], lambda b, i, m, l: H.host_random_action(m, int(seeds[b]), i))
+        fin = H.gpu_final(env)
+        for b in range(nB):
+            o = oracle.OracleEnv(A, T, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+            n, finished, guard, ok = 0, False, 0, True
+            while not finished and o.now < max_time and guard < 100000:
+                ids, t = o.next_decision()
+                o.now = t
+                o.task_update(); o.agent_update()
+                for a in ids:
+                    g = got[b]
+                    if n >= g["n_steps"] or int(g["leader"][n]) != int(a) or not np.array_equal(g["mask"][n], o.mask()):
+                        ok = False
+                        break
+                    o.agent_step(int(a), int(g["action"][n]))
+                    o.task_update(); o.agent_update()
+                    n += 1
+                if not ok:
+                    break
+                finished = o.check_finished()
+                guard += 1 if len(ids) else 20000          # zero-decider events: the shared guard ends the episode
+            checked += 1
+            is_cnt += 1
+            if ok:
+                oracle.lib().orc_finish_episode(o._h)
+                ref = o.final()
+                ok = n == got[b]["n_steps"] and (fin[b]["flags"] & 4 or (float(fin[b]["reward"]) == ref["reward"] and
+                                                                             np.array_equal(fin[b]["travel_dist"], ref["travel_dist"]) and np.array_equal(fin[b]["time_start"], ref["time_start"])))
+            if not ok:
+                bad += 1
+                print("MISMATCH individual-selection", A, T, mwt, base, b, flush=True)
+        env.close()
+print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {is_cnt} in individual-selection mode, {time.time() - t0:.0f} s")
