@@ -44,6 +44,14 @@ __host__ __device__ constexpr uint32_t align16(uint32_t x) { return (x + 15u) & 
 // in event order, up to AB_CAP per episode.  Lives in an HBM side table (touched only by the rare removal path and by the
 // terminal metrics), so calculate_waiting_time's per-agent sums (:358-364) can be accumulated in the reference's order.
 constexpr int AB_CAP = 16;
+// Agents that overflow the log are summed from a dense count table instead: u16[A][T] per env (same side allocation, after
+// the logs), cnt[a][t] = number of times task t moved agent a to its abandoned_agent list in this episode BEYOND the agent's
+// first AB_CAP abandonments (which are in the log).  Incremented with a no-return 32-bit atomic on the containing word; never
+// touched -- not even cleared -- while no agent overflows, i.e. at the reference's own constants.
+__host__ __device__ constexpr size_t abcnt_pitch(int A, int T) { return (size_t)align16((uint32_t)(2 * A * T)); }
+__host__ __device__ constexpr size_t side_bytes(int B, int A, int T) {
+    return (size_t)B * A * AB_CAP * sizeof(uint16_t) + (size_t)B * abcnt_pitch(A, T);
+}
 // Record layout as a function of (A,T); see DESIGN.md §3.  All sections 8-byte aligned.
 struct Lay {
     int A, T;
@@ -68,8 +76,8 @@ struct Lay {
     __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
     __host__ __device__ constexpr uint32_t tw() const { return rec_bytes(); }        // scratch f64[T] (LDS only)
     __host__ __device__ constexpr uint32_t aw() const { return rec_bytes() + 8 * T; }  // scratch f64[A]
-    __host__ __device__ constexpr uint32_t aux() const { return align16(rec_bytes() + 8 * T + 8 * A); }  // 16 B: side-table pointer
-    __host__ __device__ constexpr uint32_t absort() const { return aux() + 16; }     // scratch u16[A][AB_CAP]
+    __host__ __device__ constexpr uint32_t aux() const { return align16(rec_bytes() + 8 * T + 8 * A); }  // 32 B: log pointer, incremental-update state, count-table pointer
+    __host__ __device__ constexpr uint32_t absort() const { return aux() + 32; }     // scratch u16[A][AB_CAP]
     __host__ __device__ constexpr uint32_t tmx() const { return align16(absort() + 2 * AB_CAP * A); }   // scratch f64[T]
     __host__ __device__ constexpr uint32_t twords() const { return (uint32_t)(T + 63) / 64; }
     __host__ __device__ constexpr uint32_t amask() const { return tmx() + 8 * T; }                       // scratch u64[A][twords]

@@ -85,9 +85,15 @@ struct Sim {
     __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(base + L().amask()); }
     // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
     __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + L().aux()); }
-    // (pitch_A = agents per env of the side table = the batch maximum; equals A() unless the batch is ragged)
-    __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int pitch_A, int lane) const {
-        if (lane == 0) *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * pitch_A * AB_CAP;
+    __device__ __forceinline__ uint8_t* abcnt() const { return *(uint8_t* const*)(base + L().aux() + 16); }
+    // (pitch_A / pitch_T = sizes the side tables are laid out for = the batch maximum; equal A() / T() unless the batch is
+    //  ragged.  One workgroup per env: gridDim.x is the batch size, the count tables follow the logs of all envs.)
+    __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int pitch_A, int pitch_T, int lane) const {
+        if (lane == 0) {
+            *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * pitch_A * AB_CAP;
+            *(uint8_t**)(base + L().aux() + 16) = (uint8_t*)(table + (size_t)gridDim.x * pitch_A * AB_CAP) +
+                                                  (size_t)env_index * abcnt_pitch(pitch_A, pitch_T);
+        }
     }
 
     struct AMask { uint64_t w[NAW]; };
@@ -200,6 +206,7 @@ struct Sim {
                             // abandoned_agent.append(member) :265/:271; the agent stops being listed at `t`
                             const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;
                             if (nth < (uint32_t)AB_CAP) ablog()[id * AB_CAP + nth] = (uint16_t)t;
+                            else { const uint32_t ci = (uint32_t)(id * T_ + t); atomicAdd((uint32_t*)abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
                             if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
                         } else {
                             nids |= (uint64_t)id << (8 * k);
@@ -352,7 +359,6 @@ struct Sim {
         for (int a = lane; a < A_; a += WAVE) {
             const uint32_t nab = ainfo()[a] >> 16;
             const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
-            over = over || nab > (uint32_t)AB_CAP;
             uint16_t* my = absort() + a * AB_CAP;
             for (int i = 1; i < nl; i++) {                                   // in-place insertion sort by task id
                 const uint16_t v = my[i];
@@ -383,7 +389,30 @@ struct Sim {
                     s += (info & T_FEAS) ? (tmx()[tm] - mine) : ((wv > 0.) ? wv : 0.);   // :360 / :362
                 }
             }
-            s += (double)(nab - (uint32_t)nl) * mwt;
+            if (nab > (uint32_t)AB_CAP) {
+                // the log overflowed: redo this agent from the dense count table, tasks ascending, member term first and then
+                // one +max_waiting_time per abandonment by that task (:358-364), exact for any number of abandonments
+                const uint16_t* cnt = (const uint16_t*)abcnt() + a * T_;   // abandonments beyond the first AB_CAP (those are in `my`, sorted)
+                s = 0.;
+                int q = 0;
+                for (int t = 0; t < T_; t++) {
+                    if ((amask()[a * TW + (t >> 6)] >> (t & 63)) & 1ull) {
+                        const uint32_t info = tinfo()[t];
+                        const int n = (info >> 16) & 0xFF;
+                        const uint64_t x = mids()[t] ^ pat;
+                        uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                        z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
+                        const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                        const double mine = marr()[pos * T_ + t];
+                        const double wv = now - mine;
+                        s += (info & T_FEAS) ? (tmx()[t] - mine) : ((wv > 0.) ? wv : 0.);
+                    }
+                    int c = cnt[t];
+                    over = over || c == 65535;                                // saturated counter: the only inexact case left
+                    while (q < nl && my[q] == (uint16_t)t) { c++; q++; }
+                    for (int k = 0; k < c; k++) s += mwt;
+                }
+            }
             aw()[a] = s;
         }
 #ifdef DCM_PROFILE_PHASES
@@ -574,6 +603,16 @@ struct Sim {
             ts()[t] = 0.0; tf()[t] = 0.0;
 #pragma unroll
             for (int j = 0; j < M; j++) marr()[j * T() + t] = __builtin_nan("");   // empty member slots
+        }
+        {   // abandoned_agent = [] :131.  The count table (HBM, 2*A*T bytes) only holds the abandonments beyond the log's
+            // 16 per agent, so it needs clearing only after an episode in which some agent overflowed its log
+            bool spilled = false;
+            for (int a = lane; a < A(); a += WAVE) spilled = spilled || (ainfo()[a] >> 16) > (uint32_t)AB_CAP;
+            if (__any(spilled)) {
+                uint4* c = (uint4*)abcnt();
+                const int n16 = (int)(abcnt_pitch(A(), T()) / 16);
+                for (int i = lane; i < n16; i += WAVE) c[i] = uint4{0u, 0u, 0u, 0u};
+            }
         }
         for (int a = lane; a < A(); a += WAVE) {
             ax()[a] = ((const Hdr*)base)->depot_x; ay()[a] = ((const Hdr*)base)->depot_y;      // :134
@@ -876,7 +915,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
     unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    S.set_ablog(ablog, e, LP.A, lane);
+    S.set_ablog(ablog, e, LP.A, LP.T, lane);
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
@@ -936,7 +975,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
     const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
     unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, LP.A, lane);
+    S.set_ablog(ablog, e, LP.A, LP.T, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -990,7 +1029,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
     unsigned char* rec = state + (size_t)e * LP.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, LP.A, lane);
+    S.set_ablog(ablog, e, LP.A, LP.T, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
     Hdr h = load_hdr(smem);
@@ -1075,7 +1114,7 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned
     Sim<0, 0> S{eA, eT, smem};
     const Lay L = S.L();
     copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, A, lane);
+    S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
@@ -1105,7 +1144,7 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigne
     Sim<0, 0> S{eA, eT, smem};
     const Lay L = S.L();
     copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, A, lane);
+    S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
@@ -1199,7 +1238,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     hipError_t e1 = hipMalloc((void**)&h->state, bytes);
     hipError_t e2 = hipMalloc((void**)&h->summary, (size_t)params->n_envs * 8 * sizeof(double));
     if (e1 == hipSuccess && e2 == hipSuccess)
-        e2 = hipMalloc((void**)&h->ablog, (size_t)params->n_envs * params->n_agents * AB_CAP * sizeof(uint16_t));
+        e2 = hipMalloc((void**)&h->ablog, side_bytes(params->n_envs, params->n_agents, params->n_tasks));
     if (e1 != hipSuccess || e2 != hipSuccess) {
         if (h->state) (void)hipFree(h->state);
         if (h->summary) (void)hipFree(h->summary);
@@ -1208,6 +1247,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
         return fail(DCM_ERR_HIP, "dcm_create: hipMalloc failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     hipError_t e3 = hipMemset(h->state, 0, bytes);
+    if (e3 == hipSuccess) e3 = hipMemset(h->ablog, 0, side_bytes(params->n_envs, params->n_agents, params->n_tasks));
     if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); (void)hipFree(h->ablog); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
     // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS.  The limit is a
     // per-function, per-device attribute shared by every handle of the process, so it only ever grows: a later, smaller
@@ -1417,7 +1457,7 @@ int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_HANDLE(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
     *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double) +
-                 (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t);
+                 side_bytes(env->p.n_envs, env->L.A, env->L.T);
     return DCM_OK;
 }
 
@@ -1428,7 +1468,7 @@ int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
     HIP_TRY(hipMemcpyAsync(dst, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
     HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb, env->summary, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb + mb, env->ablog, (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t),
+    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb + mb, env->ablog, side_bytes(env->p.n_envs, env->L.A, env->L.T),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DCM_OK;
 }
@@ -1441,7 +1481,7 @@ int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
     HIP_TRY(hipMemcpyAsync(env->summary, (const unsigned char*)src + sb, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(env->ablog, (const unsigned char*)src + sb + mb,
-                           (size_t)env->p.n_envs * env->L.A * AB_CAP * sizeof(uint16_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                           side_bytes(env->p.n_envs, env->L.A, env->L.T), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     env->loaded = true;
     env->reset_done = true;
     return DCM_OK;

@@ -107,6 +107,7 @@ struct Fast {
                 if (lane == id) {                          // abandoned_agent.append(member) :265/:271
                     const uint32_t nth = s.ainfo >> 16;
                     if (nth < (uint32_t)AB_CAP) S.ablog()[id * AB_CAP + nth] = (uint16_t)t;
+                    else { const uint32_t ci = (uint32_t)(id * S.T() + t); atomicAdd((uint32_t*)S.abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
                     s.ainfo += 1u << 16;
                     if (s.cur == t) s.ainfo &= ~A_MEMBER;
                 }
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, KP P, un
     const Lay L = S.L();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, S.A(), lane);
+    S.set_ablog(ablog, e, S.A(), S.T(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * L.A : nullptr;

@@ -58,10 +58,10 @@ typedef enum {
 #define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T], or a task the mask forbids (feasible / status <= 0) */
 #define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members / injected follower count too large */
 #define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
-#define DCM_FLAG_WAIT_ORDER 128u /* informational, does not freeze the env: an agent was moved to abandoned_agent lists more \
-                                  * than 16 times in this episode (needs max_waiting_time << MAX_TIME); its sum_waiting_time then \
-                                  * adds the excess max_waiting_time terms last instead of in task order (env/task_env.py:363-364), \
-                                  * i.e. waiting_time may differ from the reference in the last bits */
+#define DCM_FLAG_WAIT_ORDER 128u /* informational, does not freeze the env: a per-(agent, task) abandonment counter saturated \
+                                  * (65535; RL mode) or, in route replay, an agent was moved to abandoned_agent lists more than 16 \
+                                  * times: that agent's sum_waiting_time then adds the excess max_waiting_time terms last instead \
+                                  * of in task order (env/task_env.py:363-364), i.e. it may differ in the last bits */
 #define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 
 /* dcm_params.flags: individual selection (Worker.run_test_IS, worker.py:159-198, skips get_unique_group) -- all agents
