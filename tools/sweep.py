@@ -90,12 +90,7 @@ for it in range(n_shapes):
                     f[k] = f[k][:nT[b]]
                 for k in AGENT_KEYS:
                     f[k] = f[k][:nA[b]]
-                if f["flags"] & 128:   # DCM_FLAG_WAIT_ORDER: >16 abandonments of one agent, sums equal within rounding only
-                    assert np.allclose(f["agent_wait"], refs[b]["agent_wait"], rtol=1e-12, atol=0) and \
-                        np.isclose(f["metrics"][3], refs[b]["metrics"][3], rtol=1e-12, atol=0)
-                    f["agent_wait"] = refs[b]["agent_wait"]
-                    f["metrics"] = f["metrics"].copy(); f["metrics"][3] = refs[b]["metrics"][3]
-                    wait_order += 1
+                wait_order += 1 if f["flags"] & 128 else 0   # DCM_FLAG_WAIT_ORDER (saturated abandonment counter): not expected
                 H.assert_final_matches(f, refs[b], f"{mode} {A}A{T}T mwt={mwt} base={base} env{b} ragged={ragged}")
             except AssertionError as ex:
                 bad += 1
