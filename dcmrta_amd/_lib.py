@@ -11,14 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCMRTA_HIP_LIB") or os.path.join(_HERE, "libdcmrta_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FOLLOWER_COLS = 4
 MAX_MEMBERS = 5
 MAX_AGENTS = 128
 MAX_TASKS = 1023
 
 FLAG_DONE, FLAG_FINISHED, FLAG_TRUNCATED, FLAG_BAD_ACTION, FLAG_OVERFLOW, FLAG_BAD_LEADER, FLAG_TYPE_ERROR = 1, 2, 4, 8, 16, 32, 64
-FLAG_WAIT_ORDER = 128   # informational: abandonment log of an agent overflowed, waiting sums added in a different order
+FLAG_WAIT_ORDER = 128   # informational: a per-(agent, task) abandonment counter saturated (RL mode) / replay log overflow
 
 
 class DcmParams(C.Structure):
@@ -43,7 +43,7 @@ SIGNATURES = {
     "dcm_reset": (C.c_int, [_vp] * 3),
     "dcm_observe": (C.c_int, [_vp] * 8),
     "dcm_step": (C.c_int, [_vp] * 11),
-    "dcm_rollout_random": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dcm_rollout_random": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),   # env, episodes, max_decisions, max_decisions_in, obs x3, steps, stream
     "dcm_summary": (C.c_int, [_vp] * 3),
     "dcm_env_status": (C.c_int, [_vp] * 5),
     "dcm_get_tasks": (C.c_int, [_vp] * 10),

@@ -171,15 +171,27 @@ class BatchedTaskEnv:
                                      self._stream()))
         return self._obs() if observe else None
 
-    def rollout_random(self, episodes=1, write_obs=True):
+    def rollout_random(self, episodes=1, write_obs=True, max_decisions=-1):
         """Config-2 hot path: `episodes` full random-policy episodes per env in one persistent launch.
+        max_decisions: int (all envs) or int64[B] (numpy/torch) -- decision budget of this call (< 0 = unlimited); an env that
+        runs out of budget stays at its pending decision, the obs buffers (obs()) hold what its last decision TAKEN saw.
         Returns steps int64[B] (device tensor)."""
         steps = torch.empty((self.B,), dtype=torch.int64, device=self.device)
         o = (self._agents, self._tasks, self._mask) if write_obs else (None, None, None)
+        per_env = None
+        if not isinstance(max_decisions, (int, np.integer)):
+            per_env = self._dev(max_decisions, torch.int64)
+            if per_env.numel() != self.B:
+                raise DcmError("max_decisions must be an int or int64[B]")
+            max_decisions = -1
         with torch.cuda.device(self.device):
-            check(self._lib.dcm_rollout_random(self._h, int(episodes), *[_ptr(x) for x in o], _ptr(steps),
-                                               self._stream()))
+            check(self._lib.dcm_rollout_random(self._h, int(episodes), int(max_decisions), _ptr(per_env),
+                                               *[_ptr(x) for x in o], _ptr(steps), self._stream()))
         return steps
+
+    def obs(self):
+        """The env's static observation buffers (written by the last observe / step / rollout_random call)."""
+        return self._obs()
 
     # ------------------------------------------------------------------ results
     def summary(self):

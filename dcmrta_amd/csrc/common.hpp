@@ -213,6 +213,7 @@ __device__ __noinline__ double psum_block(const double* a, int n) {
     for (; i < n; i++) res += a[i];
     return res;
 }
+static_assert(DCM_MAX_AGENTS <= 128, "per-agent sums are taken as one pairwise block");
 template <int DEPTH>
 __device__ double psum(const double* a, int n) {
     if constexpr (DEPTH == 0) {
@@ -295,7 +296,9 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "");
 
 struct dcm_env {
     dcm_params p;
-    dcm::Lay L;
+    int A = 0, T = 0;                // batch dims = p.n_agents / p.n_tasks: shapes of every array crossing the ABI
+    dcm::Lay L;                      // record layout dims (>= the batch dims: Lay{20,50} for every shape inside the reference's
+                                     // training range, so those shapes share one constant-offset kernel instantiation)
     dcm::KP kp;
     unsigned char* state = nullptr;  // [B][rec_bytes]
     double* summary = nullptr;       // [B][8]

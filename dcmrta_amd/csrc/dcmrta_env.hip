@@ -53,15 +53,50 @@ __device__ unsigned long long g_phase_cycles[16];
 #endif
 
 // ================================================================================== the simulator
-template <int CA, int CT>
+// Three kinds of instantiation:
+//   <CA, CT, false>  exact shape: sizes, record layout and lane-chunk trip counts are compile-time constants
+//   <CA, CT, true>   runtime sizes (uniform or per-env) inside the CONSTANT record layout Lay{CA,CT}: every shape with
+//                    A <= CA and T <= CT -- the reference's whole training range for <20,50> (parameters.py:15-16,
+//                    driver.py:114-115 draws a new shape every round) -- keeps constant LDS offsets and unrolled lane-chunk
+//                    loops; only the loop guards read the sizes
+//   <0, 0, false>    anything else: runtime sizes and a runtime layout Lay{pA,pT}
+template <int CA, int CT, bool RS>
 struct Sim {
     static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
-    int rA, rT;
+    static constexpr int NTC = CT ? (CT + 63) / 64 : 0;       // task lane chunks (0 = runtime)
+    static constexpr bool EXACT = (CA != 0) && !RS;
+    int rA, rT;           // this env's own sizes (ignored by the exact instantiation)
+    int pA, pT;           // record layout dims (read by the <0,0> instantiation only)
     unsigned char* base;  // record base (LDS in the env kernels)
 
-    __device__ __forceinline__ int A() const { return CA ? CA : rA; }
-    __device__ __forceinline__ int T() const { return CT ? CT : rT; }
-    __device__ __forceinline__ Lay L() const { return Lay{A(), T()}; }
+    __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }
+    __device__ __forceinline__ int T() const { return EXACT ? CT : rT; }
+    __device__ __forceinline__ Lay L() const { return Lay{CA ? CA : pA, CT ? CT : pT}; }
+    __device__ __forceinline__ int PT() const { return CT ? CT : pT; }     // pitch of the [M][T] member-arrival slots
+    // batch dims (shapes of the output arrays) given the kernel's (A,T) arguments
+    __device__ __forceinline__ static int BA(int A) { return EXACT ? CA : A; }
+    __device__ __forceinline__ static int BT(int T) { return EXACT ? CT : T; }
+    // lane-chunk loops over tasks / agents: constant trip count (fully unrolled, guard per chunk) unless the layout is runtime
+    __device__ __forceinline__ int tchunks() const { return CT ? NTC : (rT + WAVE - 1) / WAVE; }
+    __device__ __forceinline__ int achunks() const { return CA ? NAW : (rA + WAVE - 1) / WAVE; }
+    template <class F>
+    __device__ __forceinline__ void for_tasks(int lane, F&& f) const {        // f(t) for t = lane, lane + 64, ... < T
+        if constexpr (RS) {
+#pragma unroll
+            for (int c = 0; c < NTC; c++) { const int t = c * WAVE + lane; if (t < rT) f(t); }
+        } else {
+            for (int t = lane; t < T(); t += WAVE) f(t);
+        }
+    }
+    template <class F>
+    __device__ __forceinline__ void for_agents(int lane, F&& f) const {
+        if constexpr (RS) {
+#pragma unroll
+            for (int c = 0; c < NAW; c++) { const int a = c * WAVE + lane; if (a < rA) f(a); }
+        } else {
+            for (int a = lane; a < A(); a += WAVE) f(a);
+        }
+    }
     __device__ __forceinline__ double* ax() const { return (double*)(base + L().ax()); }
     __device__ __forceinline__ double* ay() const { return (double*)(base + L().ay()); }
     __device__ __forceinline__ double* arr() const { return (double*)(base + L().arr()); }
@@ -147,15 +182,11 @@ struct Sim {
     // the call only revisits the 64-task lane chunks the previous call touched (bitmask in inc_state()[1]) plus the chunk
     // of `only`; every other task is at a fixed point of task_update.  inc_state()[0] carries the number of infeasible
     // tasks for np.all(feasible) :279.
-#ifdef DCM_NO_INC
-    static constexpr bool INC = false;
-#else
     static constexpr bool INC = (CT == 0 || CT > WAVE);
-#endif
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + L().aux() + 8); }
     __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1) const {
         const double now = h.now, mwt = P.mwt;
-        const int T_ = T();
+        const int T_ = T(), PT_ = PT();
         bool allf = true, touched = false;
         auto one = [&](int t) {
             uint32_t info = tinfo()[t];
@@ -166,7 +197,7 @@ struct Sim {
             // them and every comparison against them is false, so no per-slot validity predicate is needed.
             double av[M];
 #pragma unroll
-            for (int j = 0; j < M; j++) av[j] = marr()[j * T_ + t];          // :251
+            for (int j = 0; j < M; j++) av[j] = marr()[j * PT_ + t];         // :251
             const double tfin = tf()[t], dur = tdur()[t];
             const int status = req - n;                                      // :252
             double mx = av[0], mn = av[0];
@@ -210,11 +241,11 @@ struct Sim {
                             if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
                         } else {
                             nids |= (uint64_t)id << (8 * k);
-                            marr()[k * T_ + t] = av[j];
+                            marr()[k * PT_ + t] = av[j];
                             k++;
                         }
                     }
-                    for (int j = k; j < n; j++) marr()[j * T_ + t] = __builtin_nan("");   // vacated slots
+                    for (int j = k; j < n; j++) marr()[j * PT_ + t] = __builtin_nan("");  // vacated slots
                     mids()[t] = nids;
                     tnab()[t] += (uint32_t)(n - k);
                     nn = k;
@@ -231,7 +262,7 @@ struct Sim {
         };
         bool all_feasible;
         if constexpr (!INC) {
-            for (int t = lane; t < T_; t += WAVE) one(t);
+            for_tasks(lane, one);
             all_feasible = __all(allf);
         } else {
             // st[0] = number of infeasible tasks, st[1] = lane-chunk bitmask of the tasks the previous call touched
@@ -239,11 +270,7 @@ struct Sim {
             const uint32_t nchunk = (uint32_t)(T_ + WAVE - 1) / WAVE, all = nchunk >= 32 ? ~0u : ((1u << nchunk) - 1u);
             uint32_t todo = all;
             if (only != -1 && T_ > WAVE) {
-#ifdef DCM_INC_FORCE_SINGLE   // timing probe only (wrong results): never revisit what the previous call touched
-                todo = only >= 0 ? (1u << (only >> 6)) : 0u;
-#else
                 todo = ((uint32_t)uni(st[1]) | (only >= 0 ? (1u << (only >> 6)) : 0u)) & all;
-#endif
             }
             const bool full = todo == all;
             int n_infeas = full ? 0 : uni(st[0]);
@@ -256,7 +283,7 @@ struct Sim {
                     const int req = i0 & 0xFF, n = (i0 >> 16) & 0xFF, st0 = (int)(int8_t)((i0 >> 8) & 0xFF);
                     bool chg = false;
                     double mx = __builtin_nan(""), mn = __builtin_nan("");
-                    for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * T_ + t]); mn = nanmin2(mn, marr()[j * T_ + t]); }
+                    for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * PT_ + t]); mn = nanmin2(mn, marr()[j * PT_ + t]); }
                     if (!(i0 & T_FEAS)) {
                         const int status = req - n;
                         if (status != st0) chg = true;
@@ -283,11 +310,10 @@ struct Sim {
         WSYNC();
         // depot :277-280 (np.all(feasible) is wave-uniform and false until the last task is feasible: nothing to scan before)
         if (all_feasible) {
-            const int A_ = A();
-            for (int a = lane; a < A_; a += WAVE) {
+            for_agents(lane, [&](int a) {
                 const uint32_t ai = ainfo()[a];
                 if ((ai & A_INDEPOT) && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
-            }
+            });
         }
     }
 
@@ -296,8 +322,7 @@ struct Sim {
     // cached A_MEMBER bit (set by agent_step, cleared when task_update drops the agent from that task).
     __device__ __forceinline__ void agent_update(const Hdr& h, const KP& P, int lane) const {
         const double now = h.now;
-        const int A_ = A();
-        for (int a = lane; a < A_; a += WAVE) {
+        for_agents(lane, [&](int a) {
             const int c = cur()[a];
             const int K = c < 0 ? 0 : c;
             const uint32_t info = tinfo()[K];                                 // :228
@@ -310,37 +335,37 @@ struct Sim {
                 nd()[a] = ndv;
                 if (c >= 0) ainfo()[a] = (ai & ~A_ASSIGNED) | as;            // depot leaves `assigned` untouched (Q6)
             }
-        }
+        });
     }
 
     // ------------------------------------------------------------------------------ terminal
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
     // Returns true when some agent's abandonment log overflowed (see DCM_FLAG_WAIT_ORDER).
     __device__ bool compute_waits(double now, double mwt, int lane) const {
-        const int T_ = T(), A_ = A();
+        const int T_ = T(), A_ = A(), PT_ = PT();
         const int TW = (int)L().twords();
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
         for (int i = lane; i < A_ * TW; i += WAVE) amask()[i] = 0ull;         // per agent: bitmask of the tasks listing it
         WSYNC();
-        for (int t = lane; t < T_; t += WAVE) {
+        for_tasks(lane, [&](int t) {
             const uint32_t info = tinfo()[t];
             const int n = (info >> 16) & 0xFF;
             const double ab = (double)tnab()[t] * mwt;
             double s = 0., mx = 0.;
             if (n != 0) {                                                    // :349
                 mx = marr()[t];
-                for (int j = 1; j < n; j++) { const double v = marr()[j * T_ + t]; mx = v > mx ? v : mx; }
-                if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - marr()[j * T_ + t]; }   // :351
-                else { for (int j = 0; j < n; j++) s += now - marr()[j * T_ + t]; }               // :354
+                for (int j = 1; j < n; j++) { const double v = marr()[j * PT_ + t]; mx = v > mx ? v : mx; }
+                if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - marr()[j * PT_ + t]; }   // :351
+                else { for (int j = 0; j < n; j++) s += now - marr()[j * PT_ + t]; }               // :354
             }
             tw()[t] = s + ab;                                                // :351-357
             tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
             const uint64_t ids = mids()[t];
             for (int j = 0; j < n; j++)                                      // transpose members -> per-agent task set
                 atomicOr(&amask()[(int)((ids >> (8 * j)) & 0xFF) * TW + (t >> 6)], 1ull << (t & 63));
-        }
+        });
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt1 = __builtin_readcyclecounter();
         if (lane == 0) atomicAdd(&g_phase_cycles[12], pt1 - pt0);
@@ -384,7 +409,7 @@ struct Sim {
                     uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
                     z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
                     const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
-                    const double mine = marr()[pos * T_ + tm];
+                    const double mine = marr()[pos * PT_ + tm];
                     const double wv = now - mine;
                     s += (info & T_FEAS) ? (tmx()[tm] - mine) : ((wv > 0.) ? wv : 0.);   // :360 / :362
                 }
@@ -403,7 +428,7 @@ struct Sim {
                         uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
                         z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
                         const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
-                        const double mine = marr()[pos * T_ + t];
+                        const double mine = marr()[pos * PT_ + t];
                         const double wv = now - mine;
                         s += (info & T_FEAS) ? (tmx()[t] - mine) : ((wv > 0.) ? wv : 0.);
                     }
@@ -424,11 +449,7 @@ struct Sim {
 
     // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
     // (header fields are passed by value: a by-reference Hdr would force the caller's header into scratch memory)
-#ifdef DCM_INLINE_TERMINAL
-    __device__ __forceinline__ bool terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
-#else
     __device__ __noinline__ bool terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
-#endif
         WSYNC();
         const bool over = compute_waits(now, mwt, lane);
         const int T_ = T(), A_ = A();
@@ -442,10 +463,13 @@ struct Sim {
         const unsigned long long pt2 = __builtin_readcyclecounter();
 #endif
         const double Td = (double)T_, Ad = (double)A_;
-        const double m2 = psum<4>(ts(), T_) / Td;      // np.nanmean(time_start)      worker.py:105
-        const double m3 = psum<4>(aw(), A_) / Ad;      // np.mean(agent sum_waiting)  :106
-        const double m4 = psum<4>(tdist(), A_);        // np.sum(travel_dist)         :107
-        const double m5 = psum<4>(tw(), T_) / Td;      // np.mean(task sum_waiting)   :108
+        // (numpy's pairwise sum is a single block up to 128 elements: always for agents, A <= DCM_MAX_AGENTS = 128, and for
+        //  tasks whenever the layout bounds T by 128)
+        auto tsum = [&](const double* a) { if constexpr (CT != 0 && CT <= 128) return psum_block(a, T_); else return psum<4>(a, T_); };
+        const double m2 = tsum(ts()) / Td;             // np.nanmean(time_start)      worker.py:105
+        const double m3 = psum_block(aw(), A_) / Ad;   // np.mean(agent sum_waiting)  :106
+        const double m4 = psum_block(tdist(), A_);     // np.sum(travel_dist)         :107
+        const double m5 = tsum(tw()) / Td;             // np.mean(task sum_waiting)   :108
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[14], __builtin_readcyclecounter() - pt2);
 #endif
@@ -479,7 +503,7 @@ struct Sim {
     // get_unique_group); lockstep API only.
     __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
                                             bool no_grouping = false) const {
-        const int A_ = A(), T_ = T();
+        const int A_ = A();
         for (;;) {
             WSYNC();
             // ---- D: check_finished.  np.nanmin over next_decision (:287)
@@ -497,14 +521,14 @@ struct Sim {
             if (!any) {                                                       // :368 nobody can decide any more
                 double maxarr = 0.0;
                 bool allret = true;
-                for (int a = lane; a < A_; a += WAVE) {
+                for_agents(lane, [&](int a) {
                     const double av = (cur()[a] != -2) ? arr()[a] : 0.0;     // max(arrival_time) or 0 :286
                     maxarr = av > maxarr ? av : maxarr;
                     allret = allret && (ainfo()[a] & A_RETURNED);
-                }
+                });
                 h.now = wave_nanmax(maxarr);                                  // :369
                 bool allfin = true;
-                for (int t = lane; t < T_; t += WAVE) allfin = allfin && (tinfo()[t] & T_FIN);
+                for_tasks(lane, [&](int t) { allfin = allfin && (tinfo()[t] & T_FIN); });
                 finished = __all(allret) && __all(allfin);                   // :370
             }
             if (finished) h.flags |= DCM_FLAG_FINISHED;
@@ -526,9 +550,7 @@ struct Sim {
                 for (int i = 0; i < NAW; i++) ndec += __popcll(dm[i]);
                 bool same = true;
                 double px[NAW], py[NAW];
-#ifndef DCM_NO_SINGLE_DECIDER
                 if (ndec > 1 && !no_grouping)
-#endif
                 {
                     const double x0 = ax()[first], y0 = ay()[first];
 #pragma unroll
@@ -595,30 +617,31 @@ struct Sim {
 
     // reset + clear_decisions (env/task_env.py:116-140); keeps seed, d, episodes
     __device__ __forceinline__ void reset_state(Hdr& h, int lane) const {
-        for (int t = lane; t < T(); t += WAVE) {
+        const int PT_ = PT();
+        for_tasks(lane, [&](int t) {
             const uint32_t req = tinfo()[t] & 0xFF;
             tinfo()[t] = req | (req << 8);       // status = requirements :131, members [], not feasible/finished
             tnab()[t] = 0;
             mids()[t] = 0;
             ts()[t] = 0.0; tf()[t] = 0.0;
 #pragma unroll
-            for (int j = 0; j < M; j++) marr()[j * T() + t] = __builtin_nan("");   // empty member slots
-        }
+            for (int j = 0; j < M; j++) marr()[j * PT_ + t] = __builtin_nan("");   // empty member slots
+        });
         {   // abandoned_agent = [] :131.  The count table (HBM, 2*A*T bytes) only holds the abandonments beyond the log's
             // 16 per agent, so it needs clearing only after an episode in which some agent overflowed its log
             bool spilled = false;
-            for (int a = lane; a < A(); a += WAVE) spilled = spilled || (ainfo()[a] >> 16) > (uint32_t)AB_CAP;
+            for_agents(lane, [&](int a) { spilled = spilled || (ainfo()[a] >> 16) > (uint32_t)AB_CAP; });
             if (__any(spilled)) {
                 uint4* c = (uint4*)abcnt();
                 const int n16 = (int)(abcnt_pitch(A(), T()) / 16);
                 for (int i = lane; i < n16; i += WAVE) c[i] = uint4{0u, 0u, 0u, 0u};
             }
         }
-        for (int a = lane; a < A(); a += WAVE) {
+        for_agents(lane, [&](int a) {
             ax()[a] = ((const Hdr*)base)->depot_x; ay()[a] = ((const Hdr*)base)->depot_y;      // :134
             arr()[a] = 0.0; nd()[a] = 0.0; tdist()[a] = 0.0;  // :135
             cur()[a] = -2; ainfo()[a] = 0;
-        }
+        });
         h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0;  // :139-140
     }
 
@@ -646,10 +669,9 @@ struct Sim {
                                             float* __restrict__ tk, uint8_t* __restrict__ mask) const {
         const double now = h.now;
         const double lx = ax()[leader], ly = ay()[leader];
-        const int A_ = A(), T_ = T();
         // get_current_agent_status, env/task_env.py:165-180
         if (ag) {
-            for (int a = lane; a < A_; a += WAVE) {
+            for_agents(lane, [&](int a) {
                 const int c = cur()[a];
                 const int K = c < 0 ? 0 : c;
                 const double av = arr()[a], tsK = ts()[K], durK = tdur()[K];
@@ -662,11 +684,11 @@ struct Sim {
                 row[0] = (float)travel; row[1] = (float)remaining; row[2] = (float)waiting;
                 row[3] = (float)(lx - ax()[a]); row[4] = (float)(ly - ay()[a]);
                 row[5] = (ainfo()[a] & A_ASSIGNED) ? 1.f : 0.f;
-            }
+            });
         }
         // get_current_task_status :182-190 and get_unfinished_task_mask :192-200
         bool allmasked = true;
-        for (int t = lane; t < T_; t += WAVE) {
+        for_tasks(lane, [&](int t) {
             const uint32_t info = tinfo()[t];
             const int status = (int)(int8_t)((info >> 8) & 0xFF);
             const bool unfinished = !(info & T_FEAS) && status > 0;           // :199
@@ -677,7 +699,7 @@ struct Sim {
                 row[0] = (float)status; row[1] = (float)(info & 0xFF); row[2] = (float)tdur()[t];
                 row[3] = (float)(tx()[t] - lx); row[4] = (float)(ty()[t] - ly);
             }
-        }
+        });
         allmasked = __all(allmasked);
         if (lane == 0) {
             if (mask) mask[0] = allmasked ? 0 : 1;                            // worker.py:58-61
@@ -834,7 +856,7 @@ struct Sim {
                     const int hi = __builtin_amdgcn_readlane(__double2hiint(arrv[i]), m & 63);
                     av = __hiloint2double(hi, lo);
                 }
-                if (lane == 0) marr()[pos * T_ + k] = av;
+                if (lane == 0) marr()[pos * PT() + k] = av;
             }
             if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
@@ -867,28 +889,28 @@ struct Sim {
     }
 };
 
-// Per-env dims.  A uniform batch (sizes == nullptr) uses the kernel's (A,T); a ragged batch (dcm_load_instances_ragged)
-// keeps every record at the pitch of the batch maximum but lays it out for the env's own (A_e,T_e), so the simulator
-// code is unchanged: only the runtime-shape instantiation <0,0> ever sees a ragged batch.
-template <int CA, int CT>
+// Three levels of dims.  (A,T) = batch dims: the shapes of every input / output array and the default env sizes.
+// (eA,eT) = this env's own sizes: (A,T) for a uniform batch, sizes[e] for a ragged one (dcm_load_instances_ragged).
+// (PA,PT) = layout dims of the record (Lay{PA,PT}, the same for every env of the handle, >= the batch dims): the
+// template constants, or the kernel arguments for the <0,0> instantiation.  Only the entries below an env's own sizes
+// are ever touched, so the simulator code is the same for all three kinds of instantiation (see Sim).
+template <int CA, int CT, bool RS>
 __device__ __forceinline__ void env_dims(const int32_t* sizes, int e, int A, int T, int& eA, int& eT) {
     eA = A; eT = T;
-    if constexpr (CA == 0) {
+    if constexpr (RS || CA == 0) {
         if (sizes) { eA = uni(sizes[2 * e]); eT = uni(sizes[2 * e + 1]); }
     }
 }
-template <int CA, int CT>
-__device__ __forceinline__ Lay pitch_lay(int A, int T) { return Lay{CA ? CA : A, CT ? CT : T}; }
 
 // ---------------------------------------------------------------------------------- kernels
-__global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned char* state, const double* depot,
+__global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, int PT, unsigned char* state, const double* depot,
                                                         const double* task_xy, const int32_t* req, const double* dur,
                                                         const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<0, 0>(sizes, e, A, T, eA, eT);
-    const Lay L{eA, eT};                                       // input arrays and records are pitched by the batch (A,T)
-    unsigned char* rec = state + (size_t)e * Lay{A, T}.rec_bytes();
+    env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
+    const Lay L{PA, PT};                                       // input arrays are pitched by the batch dims (A,T)
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
     double *tx = (double*)(rec + L.tx()), *ty = (double*)(rec + L.ty()), *td = (double*)(rec + L.tdur());
     uint32_t* ti = (uint32_t*)(rec + L.tinfo());
     for (int t = lane; t < eT; t += WAVE) {
@@ -904,18 +926,18 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, unsigned 
     }
 }
 
-template <int CA, int CT>
-__global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned char* state, const uint64_t* seeds,
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP P, unsigned char* state, const uint64_t* seeds,
                                                double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT> S{eA, eT, smem};
-    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
-    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    const Lay L = S.L();
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
-    S.set_ablog(ablog, e, LP.A, LP.T, lane);
+    S.set_ablog(ablog, e, S.BA(A), S.BT(T), lane);
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
@@ -929,31 +951,32 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, KP P, unsigned cha
     copy16(rec, smem, L.mut_bytes(), lane);
 }
 
-template <int CA, int CT>
-__global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* state, float* agents_out, float* tasks_out,
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
                                                  const int32_t* leader_in, const int32_t* sizes, uint32_t mode) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT> S{eA, eT, smem};
-    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
-    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    const Lay L = S.L();
+    const int BA = S.BA(A), BT = S.BT(T);
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
     Hdr h = load_hdr(smem);
-    float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
-    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
-    uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
+    float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
+    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
+    uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
     int leader = -1;
     const uint32_t flags0 = h.flags;
     if (!(h.flags & DCM_FLAG_DONE)) {
-        typename Sim<CA, CT>::AMask gm;
+        typename Sim<CA, CT, RS>::AMask gm;
         leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
     }
     if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
     else S.write_inactive_obs(lane, ag, tk, mk);
-    if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
+    if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
     if (lane == 0) {
         if (leader_out) leader_out[e] = leader;
         if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
@@ -961,21 +984,22 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, unsigned char* s
     }
 }
 
-template <int CA, int CT>
-__global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char* state, const int32_t* actions,
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
                                               uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT> S{eA, eT, smem};
-    using AMask = typename Sim<CA, CT>::AMask;
-    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
-    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    using AMask = typename Sim<CA, CT, RS>::AMask;
+    const Lay L = S.L();
+    const int BA = S.BA(A), BT = S.BT(T);
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, LP.A, LP.T, lane);
+    S.set_ablog(ablog, e, BA, BT, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -988,20 +1012,20 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e * LP.A, (mode & DCM_PARAM_NO_GROUPING) != 0, true);
+                                &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true);
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
     if (want_obs) {
         WSYNC();
-        float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
-        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
-        uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
+        float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
+        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
+        uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
         int leader = -1;
         if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0); }
         if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
         else S.write_inactive_obs(lane, ag, tk, mk);
-        if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
+        if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
         if (lane == 0) {
             if (leader_out) leader_out[e] = leader;
             if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
@@ -1016,29 +1040,37 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, KP P, unsigned char
 }
 
 // Config-2 hot path: whole episodes in one persistent launch, record resident in LDS.
-template <int CA, int CT>
-__global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, unsigned char* state, int episodes,
+// budget (per env: budget_in[e] if given, else budget_all; < 0 = unlimited): an env takes at most that many decisions in
+// this launch; when the budget runs out the env stays at the decision point it has reached (a later call -- dcm_rollout_random,
+// dcm_observe or dcm_step -- carries on from it) and the observation buffers hold what the last decision TAKEN saw.
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
-                                                        const int32_t* sizes) {
+                                                        const int32_t* sizes, int64_t budget_all, const int64_t* budget_in) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<CA, CT>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT> S{eA, eT, smem};
-    using AMask = typename Sim<CA, CT>::AMask;
-    const Lay L = S.L(), LP = pitch_lay<CA, CT>(A, T);
-    unsigned char* rec = state + (size_t)e * LP.rec_bytes();
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    using AMask = typename Sim<CA, CT, RS>::AMask;
+    const Lay L = S.L();
+    const int BA = S.BA(A), BT = S.BT(T);
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
-    S.set_ablog(ablog, e, LP.A, LP.T, lane);
+    S.set_ablog(ablog, e, BA, BT, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
     Hdr h = load_hdr(smem);
-    float* ag = agents_out ? agents_out + (size_t)e * 6 * LP.A : nullptr;
-    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (LP.T + 1) : nullptr;
-    uint8_t* mk = mask_out ? mask_out + (size_t)e * (LP.T + 1) : nullptr;
-    if constexpr (CA == 0) S.write_pad_obs(lane, LP.A, LP.T, ag, tk, mk);
+    float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
+    float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
+    uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
+    if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
     double* row = summary + (size_t)e * 8;
-    int64_t steps = 0;
+    // decisions left in this launch: a 32-bit countdown is the only loop-carried counter (steps = budget - left afterwards)
+    constexpr int NO_BUDGET = 0x7FFFFFFF;
+    int64_t bud = budget_in ? budget_in[e] : budget_all;
+    const int left0 = uni((int)((bud < 0 || bud >= NO_BUDGET) ? NO_BUDGET : bud));
+    int left = left0;
     PH_DECL;
     // key_1 = mix64(seed + GAMMA (d+1)): the argument is carried and advanced by GAMMA per decision (no 64-bit multiply,
     // and neither seed nor d stay live in the loop: d = d0 + steps afterwards)
@@ -1047,73 +1079,59 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, KP P, uns
     for (int ep = 0; ep < episodes; ep++) {
         if (h.flags & DCM_FLAG_DONE) {  // restart from the loaded instance; d keeps running
             if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) break;
+            if (left == 0) break;       // budget spent at an episode boundary: the finished episode's results stay readable
             S.reset_state(h, lane);
             S.advance(h, P, lane, row PH_PASS);
             PH_MARK(10);
         }
-        while (!(h.flags & DCM_FLAG_DONE)) {
+        // (the budget test rides on the loop's own scalar branch; testing it between observe and the action pick instead
+        //  splits the hot block and was measured 2.3 % slower)
+        while (!(h.flags & DCM_FLAG_DONE) && left != 0) {
             AMask gm;
             const uint64_t k1 = mix64(gd);
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
-#ifdef DCM_DUP_LEADER   // instruction-count probes (tools/variants.py + VARIANTS_PMC): run one pure phase twice
-            { AMask g2; volatile int l2 = S.pick_leader(h, lane, -1, k1 ^ 1, g2); (void)l2; }
-#endif
             PH_MARK(0);
             S.observe(h, lane, leader, ag, tk, mk);
-#ifdef DCM_DUP_OBSERVE
-            WSYNC(); S.observe(h, lane, leader, ag, tk, mk);
-#endif
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
-#ifdef DCM_DUP_ACTION
-            { volatile int a2 = S.pick_random_action(lane, k1 ^ 1); (void)a2; }
-#endif
-#ifdef DCM_DUP_TU
-            WSYNC(); S.task_update(h, P, lane); WSYNC();
-#endif
-#ifdef DCM_DUP_AU
-            WSYNC(); S.agent_update(h, P, lane); WSYNC();
-#endif
             PH_MARK(2);
             S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, nullptr, 0, false, false, true);
             gd += GAMMA;
-            steps++;
+            left--;
         }
+        if (left == 0) break;
     }
     PH_FLUSH(lane);
+    const int64_t steps = (int64_t)(left0 - left);
     if (lane == 0 && steps_out) steps_out[e] = steps;
-#ifndef DCM_KEEP_D
     h.d = d0 + (uint64_t)steps;   // every decision of this kernel is valid, so apply_and_advance counted exactly `steps`
-#endif
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
     copy16(rec, smem, L.mut_bytes(), lane);
 }
 
-#include "fast_rollout.hpp"
-
-__global__ __launch_bounds__(WAVE) void k_env_status(int A, int T, const unsigned char* state, int B, uint32_t* flags_out,
+__global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out) {
     const int e = blockIdx.x * WAVE + threadIdx.x;
     if (e >= B) return;
-    const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{A, T}.rec_bytes());
+    const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{PA, PT}.rec_bytes());
     if (flags_out) flags_out[e] = h->flags;
     if (dec_out) dec_out[e] = (int64_t)h->d;
     if (now_out) now_out[e] = h->now;
 }
 
-__global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned char* state, uint8_t* finished,
+__global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
                                                    int32_t* n_abandoned, uint16_t* ablog, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<0, 0>(sizes, e, A, T, eA, eT);
-    Sim<0, 0> S{eA, eT, smem};
+    env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
+    Sim<0, 0, false> S{eA, eT, PA, PT, smem};
     const Lay L = S.L();
-    copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
+    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
@@ -1133,17 +1151,17 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, KP P, unsigned
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigned char* state, double* sum_wait,
+__global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int PT, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
                                                     int32_t* current, int32_t* pending, uint16_t* ablog,
                                                     const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
-    env_dims<0, 0>(sizes, e, A, T, eA, eT);
-    Sim<0, 0> S{eA, eT, smem};
+    env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
+    Sim<0, 0, false> S{eA, eT, PA, PT, smem};
     const Lay L = S.L();
-    copy16_in(smem, state + (size_t)e * Lay{A, T}.rec_bytes(), L.rec_bytes(), lane);
+    copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
@@ -1166,14 +1184,13 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, KP P, unsigne
 }
 
 // task['members'] of every task, in list order (env/task_env.py:80): ids_out[B][T][DCM_MAX_MEMBERS], -1 padded
-__global__ void k_get_members(int A, int T, const unsigned char* state, int B, int16_t* ids_out, const int32_t* sizes) {
+__global__ void k_get_members(int T, int PA, int PT, const unsigned char* state, int B, int16_t* ids_out, const int32_t* sizes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * T) return;
     const int e = (int)(i / T), t = (int)(i % T);
-    int eA = A, eT = T;
-    if (sizes) { eA = sizes[2 * e]; eT = sizes[2 * e + 1]; }
-    const Lay L{eA, eT};
-    const unsigned char* rec = state + (size_t)e * Lay{A, T}.rec_bytes();
+    const int eT = sizes ? sizes[2 * e + 1] : T;
+    const Lay L{PA, PT};
+    const unsigned char* rec = state + (size_t)e * L.rec_bytes();
     uint64_t ids = 0;
     int n = 0;
     if (t < eT) {
@@ -1193,21 +1210,27 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
 }
 
 // ---------------------------------------------------------------------------------- host side
-// shape dispatch: BASELINE shapes get the constant-offset instantiation
-#define DISPATCH_SHAPE(A, T, CALL)                                       \
-    do {                                                                 \
-        if ((A) == 20 && (T) == 50) { CALL(20, 50); }                    \
-        else if ((A) == 50 && (T) == 200) { CALL(50, 200); }             \
-        else if ((A) == 100 && (T) == 500) { CALL(100, 500); }           \
-        else { CALL(0, 0); }                                             \
+// Instantiations: the three BASELINE shapes exactly; <20,50,runtime sizes> for every other shape (uniform or ragged) inside
+// the reference's training range A <= 20, T <= 50 (parameters.py:15-16); <0,0> for the rest.
+#define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(50, 200, false); X(100, 500, false); X(0, 0, false)
+#define DISPATCH_ENV(env, CALL)                                                                        \
+    do {                                                                                               \
+        const dcm_env* e_ = (env);                                                                     \
+        const bool exact_ = !e_->sizes && e_->A == e_->L.A && e_->T == e_->L.T;                        \
+        if (e_->L.A == 20 && e_->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } } \
+        else if (exact_ && e_->A == 50 && e_->T == 200) { CALL(50, 200, false); }                      \
+        else if (exact_ && e_->A == 100 && e_->T == 500) { CALL(100, 500, false); }                    \
+        else { CALL(0, 0, false); }                                                                    \
     } while (0)
+// kernel arguments every env kernel starts with: batch dims, layout dims
+#define DIMS(env) (env)->A, (env)->T, (env)->L.A, (env)->L.T
 
-// a ragged batch (per-env sizes) always takes the runtime-shape instantiation
-#define DISPATCH_ENV(env, CALL)                                          \
-    do {                                                                 \
-        if ((env)->sizes) { CALL(0, 0); }                                \
-        else DISPATCH_SHAPE((env)->L.A, (env)->L.T, CALL);               \
-    } while (0)
+// dcm_create / dcm_destroy run on the handle's device but leave the caller's current device as they found it
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 }  // namespace
 
@@ -1226,11 +1249,12 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(DCM_ERR_NO_DEVICE, "dcm_create: no HIP device (this library has no CPU path)");
     if (params->device < 0 || params->device >= ndev) return fail(DCM_ERR_INVALID, "dcm_create: bad device ordinal");
-    HIP_TRY(hipSetDevice(params->device));
+    DeviceGuard guard(params->device);
     dcm_env* h = new (std::nothrow) dcm_env();
     if (!h) return fail(DCM_ERR_INVALID, "dcm_create: out of host memory");
     h->p = *params;
-    h->L = Lay{params->n_agents, params->n_tasks};
+    h->A = params->n_agents; h->T = params->n_tasks;
+    h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : Lay{h->A, h->T};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
     if (h->L.lds_bytes() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
@@ -1257,15 +1281,13 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     int lds = (int)h->L.lds_bytes();
     if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
     lds_limit[dev_slot] = lds;
-#define SET_ATTR(CA, CT)                                                                                             \
-    (void)hipFuncSetAttribute((const void*)k_reset<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
-    (void)hipFuncSetAttribute((const void*)k_observe<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
-    (void)hipFuncSetAttribute((const void*)k_step<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
-    (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-    SET_ATTR(20, 50); SET_ATTR(50, 200); SET_ATTR(100, 500); SET_ATTR(0, 0);
+#define SET_ATTR(CA, CT, RS)                                                                                             \
+    (void)hipFuncSetAttribute((const void*)k_reset<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+    (void)hipFuncSetAttribute((const void*)k_observe<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      \
+    (void)hipFuncSetAttribute((const void*)k_step<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);         \
+    (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    FOR_EACH_INSTANCE(SET_ATTR);
 #undef SET_ATTR
-    (void)hipFuncSetAttribute((const void*)k_rollout_fast<20, 50>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)k_rollout_fast<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_get_agents, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = h;
@@ -1274,7 +1296,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
 
 int dcm_destroy(dcm_env* env) {
     if (!env) return DCM_OK;
-    (void)hipSetDevice(env->p.device);
+    DeviceGuard guard(env->p.device);
     if (env->state) (void)hipFree(env->state);
     if (env->summary) (void)hipFree(env->summary);
     if (env->ablog) (void)hipFree(env->ablog);
@@ -1291,7 +1313,7 @@ int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy,
     CHECK_ENV(env);
     if (!depot || !task_xy || !req || !dur) return fail(DCM_ERR_INVALID, "dcm_load_instances: null array");
     if (env->sizes) { HIP_TRY(hipFree(env->sizes)); env->sizes = nullptr; }   // back to a uniform batch (hipFree synchronises)
-    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, env->L.A, env->L.T, env->state, depot, task_xy,
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, depot, task_xy,
                        req, dur, (const int32_t*)nullptr);
     LAUNCH_OK();
     env->loaded = true;
@@ -1308,14 +1330,14 @@ int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* t
     env->sizes_host.resize((size_t)2 * B);
     for (int e = 0; e < B; e++) {
         const int a = n_agents_host[e], t = n_tasks_host[e];
-        if (a < 1 || a > env->L.A || t < 1 || t > env->L.T)
+        if (a < 1 || a > env->A || t < 1 || t > env->T)
             return fail(DCM_ERR_INVALID, "dcm_load_instances_ragged: need 1 <= n_agents[e] <= A and 1 <= n_tasks[e] <= T");
         env->sizes_host[2 * (size_t)e] = a; env->sizes_host[2 * (size_t)e + 1] = t;
     }
     if (!env->sizes) HIP_TRY(hipMalloc((void**)&env->sizes, (size_t)2 * B * sizeof(int32_t)));
     HIP_TRY(hipMemcpyAsync(env->sizes, env->sizes_host.data(), (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
-    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, env->L.A, env->L.T, env->state, depot, task_xy,
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, depot, task_xy,
                        req, dur, (const int32_t*)env->sizes);
     LAUNCH_OK();
     env->loaded = true;
@@ -1327,14 +1349,14 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     CHECK_ENV(env);
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
-#define CALL(CA, CT)                                                                                                  \
-    hipLaunchKernelGGL((k_reset<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
+#define CALL(CA, CT, RS)                                                                                              \
+    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp, \
                        env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
     if (env->log.len)
-        HIP_TRY(hipMemsetAsync(env->log.len, 0, (size_t)env->p.n_envs * env->L.A * sizeof(int32_t), (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(env->log.len, 0, (size_t)env->p.n_envs * env->A * sizeof(int32_t), (hipStream_t)stream));
     env->reset_done = true;
     return DCM_OK;
 }
@@ -1352,8 +1374,8 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
                 uint8_t* active_out, const int32_t* leader_in, void* stream) {
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
-#define CALL(CA, CT)                                                                                                    \
-    hipLaunchKernelGGL((k_observe<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,     \
+#define CALL(CA, CT, RS)                                                                                                \
+    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env),          \
                        env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
                        (const int32_t*)env->sizes, env->p.flags)
     DISPATCH_ENV(env, CALL);
@@ -1370,8 +1392,8 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (!actions) return fail(DCM_ERR_INVALID, "dcm_step: null actions");
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
-#define CALL(CA, CT)                                                                                                 \
-    hipLaunchKernelGGL((k_step<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp, \
+#define CALL(CA, CT, RS)                                                                                             \
+    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp, \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
                        active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes)
     DISPATCH_ENV(env, CALL);
@@ -1380,26 +1402,16 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     return DCM_OK;
 }
 
-int dcm_rollout_random(dcm_env* env, int32_t episodes, float* agents_out, float* tasks_out, uint8_t* mask_out,
-                       int64_t* steps_out, void* stream) {
+int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, const int64_t* max_decisions_in,
+                       float* agents_out, float* tasks_out, uint8_t* mask_out, int64_t* steps_out, void* stream) {
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
-#define CALL(CA, CT)                                                                                                  \
-    hipLaunchKernelGGL((k_rollout_random<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, \
+#define CALL(CA, CT, RS)                                                                                              \
+    hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
-                       (const int32_t*)env->sizes)
-#define CALL_FAST(CA, CT)                                                                                             \
-    hipLaunchKernelGGL((k_rollout_fast<CA, CT>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T,  \
-                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog)
-    if (env->L.A <= 64 && env->L.T <= 64 && !env->sizes && getenv("DCM_FAST_ROLLOUT")) {
-        // opt-in register-resident kernel: lane t owns task t, lane a owns agent a (fast_rollout.hpp); parity-green but
-        // measured 3 % slower than the LDS-resident kernel at 20A/50T (0.695 vs 0.675 ms/launch), so not the default
-        if (env->L.A == 20 && env->L.T == 50) { CALL_FAST(20, 50); } else { CALL_FAST(0, 0); }
-    } else {
-        DISPATCH_ENV(env, CALL);
-    }
-#undef CALL_FAST
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in)
+    DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
     return DCM_OK;
@@ -1417,7 +1429,7 @@ int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, do
     CHECK_ENV(env);
     const int B = env->p.n_envs;
     hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
-                       env->state, B, flags_out, decisions_out, now_out);
+                       env->state, B, flags_out, decisions_out, now_out);   // (layout dims: only the record pitch matters)
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1425,7 +1437,7 @@ int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, do
 int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* time_start, double* time_finish,
                   double* sum_wait, int32_t* status, int32_t* n_members, int32_t* n_abandoned, void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
+    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp,
                        env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned,
                        env->ablog, (const int32_t*)env->sizes);
     LAUNCH_OK();
@@ -1436,7 +1448,7 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
                    double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, int32_t* pending_group,
                    void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, env->L.A, env->L.T, env->kp,
+    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
                        pending_group, env->ablog, (const int32_t*)env->sizes);
     LAUNCH_OK();
@@ -1446,8 +1458,8 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
 int dcm_get_members(dcm_env* env, int16_t* ids_out, void* stream) {
     CHECK_ENV(env);
     if (!ids_out) return fail(DCM_ERR_INVALID, "dcm_get_members: null ids_out");
-    const int64_t n = (int64_t)env->p.n_envs * env->L.T;
-    hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->L.A, env->L.T,
+    const int64_t n = (int64_t)env->p.n_envs * env->T;
+    hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->T, env->L.A, env->L.T,
                        env->state, env->p.n_envs, ids_out, (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
@@ -1457,7 +1469,7 @@ int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
     CHECK_HANDLE(env);
     if (!bytes_out) return fail(DCM_ERR_INVALID, "null bytes_out");
     *bytes_out = (size_t)env->p.n_envs * env->L.rec_bytes() + (size_t)env->p.n_envs * 8 * sizeof(double) +
-                 side_bytes(env->p.n_envs, env->L.A, env->L.T);
+                 side_bytes(env->p.n_envs, env->A, env->T);
     return DCM_OK;
 }
 
@@ -1468,7 +1480,7 @@ int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
     HIP_TRY(hipMemcpyAsync(dst, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
     HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb, env->summary, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb + mb, env->ablog, side_bytes(env->p.n_envs, env->L.A, env->L.T),
+    HIP_TRY(hipMemcpyAsync((unsigned char*)dst + sb + mb, env->ablog, side_bytes(env->p.n_envs, env->A, env->T),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DCM_OK;
 }
@@ -1481,7 +1493,7 @@ int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
     HIP_TRY(hipMemcpyAsync(env->summary, (const unsigned char*)src + sb, mb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(env->ablog, (const unsigned char*)src + sb + mb,
-                           side_bytes(env->p.n_envs, env->L.A, env->L.T), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                           side_bytes(env->p.n_envs, env->A, env->T), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     env->loaded = true;
     env->reset_done = true;
     return DCM_OK;

@@ -229,14 +229,14 @@ struct Rep {
     }
 };
 
-__global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int MR, RP P, const unsigned char* state,
+__global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, int MR, RP P, const unsigned char* state,
                                                 const int32_t* routes, const int32_t* route_len, int route_cap,
                                                 double* summary, int64_t* steps_out, uint32_t* flags_out,
                                                 uint8_t* finished, double* time_start, double* time_finish,
                                                 double* task_wait, int32_t* n_members, double* agent_wait,
                                                 double* travel_dist, uint8_t* returned) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    const Lay EL{A, T};
+    const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
     const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
     Rep R{A, T, MR, smem, RLay{A, T, MR}};
     const Hdr* gh = (const Hdr*)rec;
@@ -490,10 +490,9 @@ int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_le
     CHECK_ENV(env);
     if (!routes || !route_len || route_cap < 1) return fail(DCM_ERR_INVALID, "dcm_load_routes: bad argument");
     if (member_cap < 1 || member_cap > MR_MAX) return fail(DCM_ERR_INVALID, "dcm_load_routes: member_cap must be in 1..32");
-    if (replay_lds_bytes(env->L.A, env->L.T, member_cap) > 160 * 1024)
+    if (replay_lds_bytes(env->A, env->T, member_cap) > 160 * 1024)
         return fail(DCM_ERR_INVALID, "dcm_load_routes: replay state does not fit the 160 KiB LDS; lower member_cap");
-    HIP_TRY(hipSetDevice(env->p.device));
-    const size_t nr = (size_t)env->p.n_envs * env->L.A * route_cap, nl = (size_t)env->p.n_envs * env->L.A;
+    const size_t nr = (size_t)env->p.n_envs * env->A * route_cap, nl = (size_t)env->p.n_envs * env->A;   // (CHECK_ENV: the handle's device is current)
     if (env->routes) { (void)hipFree(env->routes); env->routes = nullptr; }
     if (env->route_len) { (void)hipFree(env->route_len); env->route_len = nullptr; }
     HIP_TRY(hipMalloc((void**)&env->routes, nr * sizeof(int32_t)));
@@ -512,10 +511,10 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_instances first");
     if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
     if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");
-    const uint32_t lds = replay_lds_bytes(env->L.A, env->L.T, env->member_cap);
+    const uint32_t lds = replay_lds_bytes(env->A, env->T, env->member_cap);
     (void)hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     RP P{100.0, 200.0, reactive ? 1 : 0};  // env/task_env.py:564-565
-    hipLaunchKernelGGL(k_replay, GRID(env), lds, (hipStream_t)stream, env->L.A, env->L.T, env->member_cap, P, env->state,
+    hipLaunchKernelGGL(k_replay, GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T, env->member_cap, P, env->state,
                        env->routes, env->route_len, env->route_cap, env->summary, steps_out, flags_out, finished, time_start,
                        time_finish, task_wait, n_members, agent_wait, travel_dist, returned);
     LAUNCH_OK();

@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     DCM_OK_(dcm_create(&p, &env));
     DCM_OK_(dcm_load_instances(env, d_depot, d_xy, d_req, d_dur, st));
     DCM_OK_(dcm_reset(env, d_seeds, st));
-    DCM_OK_(dcm_rollout_random(env, 1, nullptr, nullptr, nullptr, d_steps, st));
+    DCM_OK_(dcm_rollout_random(env, 1, -1, nullptr, nullptr, nullptr, nullptr, d_steps, st));
     DCM_OK_(dcm_summary(env, d_sum, st));
     HIP_OK(hipStreamSynchronize(st));
     std::vector<int64_t> steps(B);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCM_ABI_VERSION 1
+#define DCM_ABI_VERSION 2
 
 typedef struct dcm_env dcm_env; /* opaque */
 
@@ -148,10 +148,17 @@ int dcm_set_route_log(dcm_env *env, int16_t *route_task, double *route_arrival, 
  * policy inside ONE persistent launch (worker.py:45-87 with the action drawn from slot 1 of the
  * protocol); the observation tensors + mask are produced at every decision exactly as dcm_observe
  * does and written to agents_out/tasks_out/mask_out (nullable: skip the stores).  Envs restart
- * from their loaded instance between episodes; the decision counter keeps running.
- * steps_out[B] i64: decisions taken by each env over all episodes. */
-int dcm_rollout_random(dcm_env *env, int32_t episodes, float *agents_out, float *tasks_out, uint8_t *mask_out,
-                       int64_t *steps_out, void *stream);
+ * from their loaded instance between episodes; the decision counter keeps running.  An env that is in the middle of an
+ * episode when the call starts first plays that episode to its end (it counts as one of the `episodes`).
+ * Decision budget: max_decisions_in[B] i64 (nullable device array) or, when NULL, the scalar max_decisions -- an env
+ * takes at most that many decisions in this call (< 0 = unlimited).  When the budget runs out the env stays at the
+ * decision point it has reached with nothing of the pending decision applied (dcm_observe gives its observation;
+ * dcm_step / a further dcm_rollout_random carry on from there with identical results), and agents_out / tasks_out /
+ * mask_out hold what the kernel stored for the LAST DECISION TAKEN -- which is how the parity tests compare the
+ * persistent kernel's own per-decision stores with the oracle at arbitrary decision indices.
+ * steps_out[B] i64: decisions taken by each env in this call. */
+int dcm_rollout_random(dcm_env *env, int32_t episodes, int64_t max_decisions, const int64_t *max_decisions_in,
+                       float *agents_out, float *tasks_out, uint8_t *mask_out, int64_t *steps_out, void *stream);
 
 /* Terminal results of the last finished episode (worker.py:87,103-108):
  * out[B,8] f64 = reward(-makespan), n_finished_tasks, success_rate, makespan, time_cost,
@@ -203,7 +210,9 @@ int dcm_execute_routes(dcm_env *env, int32_t reactive, int64_t *steps_out, uint3
                        double *time_start, double *time_finish, double *task_wait, int32_t *n_members,
                        double *agent_wait, double *travel_dist, uint8_t *returned, void *stream);
 
-/* bytes of canonical state per env: S = 64 + 48*A + 96*T */
+/* bytes of canonical state per env: S = 64 + 48*A + 96*T.  (Handles with A <= 20 and T <= 50 keep their
+ * records in the fixed Lay{20,50} layout -- 5824 B per env -- so that every shape of the reference's training range runs
+ * the same constant-offset kernels; dcm_state_bytes reports what is really allocated.) */
 int dcm_record_bytes(dcm_env *env, size_t *bytes_out);
 
 #ifdef __cplusplus

@@ -1,5 +1,5 @@
 """-m gpu: randomised parity sweep (a short run of tools/sweep.py): random shapes, waiting limits and durations; the persistent
-kernel, the opt-in register-resident kernel and the lockstep API against the oracle, every terminal quantity bit-exact."""
+kernel in one launch and in randomly budgeted launches, and the lockstep API against the oracle, every terminal quantity bit-exact."""
 import os
 import subprocess
 import sys

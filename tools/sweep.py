@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU box: many (A, T, seed) shapes, persistent rollout kernel (default and opt-in fast
+"""Randomised parity sweep on the GPU box: many (A, T, seed) shapes, persistent rollout kernel (one launch and budgeted launches
 kernel) and lockstep API against the oracle.  Developer tool; prints the number of envs checked and any mismatch."""
 import os
 import sys
@@ -52,13 +52,7 @@ for it in range(n_shapes):
         a, t = int(nA[b]), int(nT[b])
         o = oracle.OracleEnv(a, t, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
         refs.append(o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False))
-    for mode in ("rollout", "fast", "lockstep"):
-        if mode == "fast":
-            if A > 64 or T > 64 or ragged:
-                continue
-            os.environ["DCM_FAST_ROLLOUT"] = "1"
-        else:
-            os.environ.pop("DCM_FAST_ROLLOUT", None)
+    for mode in ("rollout", "budget", "lockstep"):
         env = BatchedTaskEnv(B, A, T, max_waiting_time=mwt, max_time=max_time).load_instances(**inst)
         if mode == "lockstep":
             if it % 4 and not (ragged and it % 2):
@@ -78,6 +72,15 @@ for it in range(n_shapes):
                 if not ok:
                     bad += 1
                     print("MISMATCH per-step outputs", A, T, mwt, base, b, "ragged", ragged, flush=True)
+        elif mode == "budget":
+            # the same episode in budgeted launches (random per-env decision budgets): stops anywhere, carries on identically
+            env.reset(seeds, observe=False)
+            steps = np.zeros(B, np.int64)
+            nref = np.array([r["n_steps"] for r in refs], np.int64)
+            for _ in range(3):   # (budgets stay inside the episode: a finished env would start its next episode)
+                bud = np.clip(np.minimum(rng.integers(0, 60, B), nref - 1 - steps), 0, None).astype(np.int64)
+                steps += env.rollout_random(1, max_decisions=bud).cpu().numpy()
+            steps += env.rollout_random(1).cpu().numpy()
         else:
             env.reset(seeds, observe=False)
             steps = env.rollout_random(1).cpu().numpy()
