@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/sec of the batched coalition-formation + routing rollout (BASELINE.json metric).
 
-One bench "step" = one pass of the hot path over one batch: every env of the batch plays 3 consecutive complete
-episodes (auto-reset to the same instance, the decision counter keeps running) under the
-uniform-random valid policy inside ONE launch of the persistent HIP kernel (dcm_rollout_random), with the observation
-tensors + mask built and stored at every decision.  value = decisions taken by all envs on all
-ranks / wall time, inputs (instances, seeds, state) resident in HBM before the timed region starts.
+One bench "step" = one pass of the hot path over one batch: every env of the batch plays its consecutive complete
+episodes (3 per env, auto-reset to the same instance, the decision counter keeps running) under
+the uniform-random valid policy inside the persistent HIP kernel (dcm_rollout_random), with the observation tensors + mask
+built and stored at every decision.  value = decisions taken by all envs on all ranks / wall time, inputs (instances,
+seeds, state) resident in HBM before the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4] [--streams S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload at N=1 = BASELINE.json configs[1]: 4096 parallel envs, 20 agents / 50 tasks, random policy, HIP env
-only.  N>1: the env batch is sharded (4096 envs per GPU, weak scaling), no data-path collective; one RCCL
-all-gather of the per-env episode returns per pass (the analogue of ray.get in driver.py:129-130).
+--config 2 (default) = BASELINE.json configs[1]: 4096 parallel envs per GPU, 20 agents / 50 tasks, random policy, HIP env
+only; N > 1 shards more envs (weak scaling).  --config 4 = BASELINE.json configs[3]: 65 536 envs of 50A/200T in total,
+sharded over the N ranks by contiguous blocks (strong scaling), one episode per env per pass.  Either way there is no
+data-path collective; one RCCL all-gather of the per-env episode returns per pass (the analogue of ray.get in
+driver.py:129-130), issued asynchronously so that it overlaps with the next pass.
+
+--streams S: the rank's env block is cut into S contiguous sub-batches, each with its own handle and HIP stream.  A pass
+is then S launches; a launch lasts as long as its slowest env, and with several independent streams one sub-batch's tail
+(few live waves) overlaps with the body of the others instead of idling the machine (DESIGN.md §6 "launch tail").
 """
 import argparse
 import json
@@ -20,17 +26,30 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The sub-batches of a pass run on separate HIP streams; the runtime maps streams onto 4 hardware queues by default and
+# kernels that share a queue serialise.  Must be set before the HIP runtime initialises (measured on MI355X, 4096 envs:
+# 4 streams on 4 queues 5.3e8 steps/s, on 8 queues 9.5e8).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
 from dcmrta_amd.choice import env_seeds  # noqa: E402
-from dcmrta_amd.dist import DistContext  # noqa: E402
+from dcmrta_amd.dist import DistContext, shard_range  # noqa: E402
 from dcmrta_amd.instances import generate_batch  # noqa: E402
-from dcmrta_amd.roofline import HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step  # noqa: E402
+from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, N_SIMD, PEAK_CLOCK_HZ, algorithmic_bytes_per_step,  # noqa: E402
+                                 load_counters)
+
+CONFIGS = {
+    # name: (envs, agents, tasks, episodes per pass, scaling, label)
+    "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]"),
+    "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]"),
+}
+DEFAULT_STREAMS = 4
 
 
 def usable_cores():
@@ -56,32 +75,43 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(inst, seeds, A, target_core_seconds=20.0):
-    """The oracle (bit-parity C restatement of the reference) on the host cores: baseline, not target."""
+def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
+    """The oracle (bit-parity C restatement of the reference) on the host cores: baseline, not target.  Timed on all
+    usable cores and on 8 threads (the reference runs NUM_META_AGENT = 8 one-core Ray actors, parameters.py:4,
+    runner.py:74)."""
     import oracle
     oracle.build()
     cores = usable_cores()
     B = len(seeds)
-    # calibrate on a small slice, then size the sample to ~target_core_seconds of CPU work
+    # calibrate on a small slice, then size each sample to ~target_core_seconds of CPU work
     t0 = time.perf_counter()
     n0, *_ = oracle.batch_rollout(inst["depot"][:64], inst["task_xy"][:64], inst["req"][:64], inst["dur"][:64], seeds[:64], A,
                                   episodes=1, threads=1)
     rate1 = n0 / (time.perf_counter() - t0)
     per_episode = n0 / 64.0
     episodes = int(max(1, min(64, round(target_core_seconds * rate1 / (per_episode * B)))))
-    t0 = time.perf_counter()
-    n, *_ = oracle.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"], seeds, A, episodes=episodes,
-                                 threads=cores)
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="steps/s", cores=cores, kind="port",
+
+    def timed(threads):
+        t0 = time.perf_counter()
+        n, *_ = oracle.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"], seeds, A, episodes=episodes,
+                                     threads=threads)
+        return n, n / (time.perf_counter() - t0)
+    n, rate_all = timed(cores)
+    t8 = min(8, cores)
+    _, rate8 = timed(t8)
+    return dict(value=rate_all, unit="steps/s", cores=cores, kind="port",
                 sample=f"{B} envs x {episodes} episodes ({n} decisions) of the same instances/seeds, oracle C port, "
                        f"{cores} threads (= usable host CPUs: cpu_count {os.cpu_count()}, cgroup/affinity limit {cores}), "
-                       f"one env per thread")
+                       f"one env per thread; timed again on {t8} threads",
+                at_8_threads=dict(value=rate8, unit="steps/s", cores=t8,
+                                  note="mirror of the reference's NUM_META_AGENT = 8 one-core actors (runner.py:74)"),
+                single_thread_rate=rate1)
 
 
 def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
     """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
-    decision: measured at a batch that fills the machine, HIP events around dcm_step only, device-side random policy."""
+    decision: the HBM roofline of this path is quoted on it, at a batch that fills the machine, HIP events around
+    dcm_step only, device-side random policy."""
     env = BatchedTaskEnv(B, A, T, device=str(dev)).load_instances(**generate_batch(B, A, T, base_seed=0))
     obs = env.reset(env_seeds(0, 0, B))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -93,9 +123,26 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
     torch.cuda.synchronize(dev)
     ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
     Wb = algorithmic_bytes_per_step(A, T)
-    return {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
-            "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-            "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9)}
+    c = load_counters(f"k_step:{B}x{A}A{T}T")
+    out = {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
+           "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+           "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9), "algorithmic_bytes_per_launch": B * Wb,
+           "traffic": c.get("hbm_bytes_per_launch") if c else None, "counters_source": c.get("source") if c else None}
+    env.close()
+    return out
+
+
+class SubBatch:
+    """One contiguous block of the rank's envs: its own handle and (for more than one sub-batch) its own HIP stream."""
+
+    def __init__(self, first, B, A, T, dev, stream):
+        self.first, self.B, self.stream = first, B, stream
+        self.inst = generate_batch(B, A, T, base_seed=0, first=first)
+        self.seeds = env_seeds(0, first, B)
+        self.env = BatchedTaskEnv(B, A, T, device=str(dev))
+        self.env.load_instances(**self.inst)
+        self.env.reset(self.seeds, observe=False)
+        self.counts, self.ev, self.warm = [], [], []
 
 
 def main():
@@ -103,91 +150,162 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--agents", type=int, default=20)
-    ap.add_argument("--tasks", type=int, default=50)
-    ap.add_argument("--episodes", type=int, default=3,
-                    help="consecutive episodes per env per pass (SURVEY.md §8d config 2: 3, auto-reset to the same instance)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="2")
+    ap.add_argument("--envs", type=int, default=None, help="config 2: envs per GPU; config 4: envs in total")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--tasks", type=int, default=None)
+    ap.add_argument("--episodes", type=int, default=None, help="consecutive episodes per env per pass")
+    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS, help="sub-batches (HIP streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("envs", "agents", "tasks", "episodes"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    A, T, EP = cfg["agents"], cfg["tasks"], cfg["episodes"]
 
     ctx = DistContext.from_env(expected_world=args.gpus)
     dev = ctx.device
     torch.cuda.set_device(dev)
-    B, A, T = args.envs, args.agents, args.tasks
-    first = ctx.rank * B
-    inst = generate_batch(B, A, T, base_seed=0, first=first)
-    seeds = env_seeds(0, first, B)
-    env = BatchedTaskEnv(B, A, T, device=str(dev))
-    env.load_instances(**inst)
-    env.reset(seeds, observe=False)
+    if cfg["scaling"] == "weak":
+        first, B = ctx.rank * cfg["envs"], cfg["envs"]
+        n_total = cfg["envs"] * ctx.world
+    else:
+        n_total = cfg["envs"]
+        first, hi = shard_range(n_total, ctx.rank, ctx.world)
+        B = hi - first
+    S = max(1, min(args.streams, B))
+    main_stream = torch.cuda.current_stream(dev)
+    subs = []
+    for s in range(S):
+        lo, hi = shard_range(B, s, S)
+        subs.append(SubBatch(first + lo, hi - lo, A, T, dev, main_stream if S == 1 else torch.cuda.Stream(device=dev)))
+    torch.cuda.synchronize(dev)
+    returns = [torch.empty((B,), dtype=torch.float64, device=dev) for _ in range(2)]   # double-buffered per-pass returns
 
-    def one_pass():
-        steps = env.rollout_random(episodes=args.episodes, write_obs=not args.no_obs)
-        if ctx.world > 1:
-            ctx.all_gather_returns(env.summary()[:, 0])
-        return steps
+    def one_pass(k, timed):
+        """Every sub-batch plays its episodes (one persistent launch each); N > 1: exchange the episode returns."""
+        done = []
+        for sb in subs:
+            with torch.cuda.stream(sb.stream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                steps = sb.env.rollout_random(episodes=EP, write_obs=not args.no_obs)
+                e1.record()
+                if timed:
+                    sb.counts.append(steps)
+                    sb.ev.append((e0, e1))
+                else:
+                    sb.warm.append(steps)
+                if ctx.active:
+                    lo = sb.first - first
+                    returns[k & 1][lo:lo + sb.B].copy_(sb.env.summary()[:, 0])
+                    d = torch.cuda.Event()
+                    d.record()
+                    done.append(d)
+        if ctx.active:
+            for d in done:
+                main_stream.wait_event(d)
+            # per-episode return exchange on RCCL's stream; nothing on the env streams waits for it
+            return ctx.all_gather_returns(returns[k & 1], async_op=True, n_total=n_total)
+        return None
 
-    for _ in range(args.warmup):
-        one_pass()
+    for w in range(args.warmup):
+        g = one_pass(w, False)
+        if g is not None and g[1] is not None:
+            g[1].wait()
+    torch.cuda.synchronize(dev)
+    if ctx.active:
+        # the gathered vector is the rank-major concatenation of the per-rank return vectors on EVERY rank
+        local = torch.cat([sb.env.summary()[:, 0] for sb in subs])
+        ctx.verify_gather(ctx.all_gather_returns(local, n_total=n_total), local, first)
     K = args.steps
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    counts, pending = [], []
+    pending = []
     ctx.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(K):
-        ev0[k].record()
-        steps = env.rollout_random(episodes=args.episodes, write_obs=not args.no_obs)
-        ev1[k].record()
-        if ctx.world > 1:   # per-episode return exchange; overlaps with the next pass (nothing depends on it)
-            pending.append(ctx.all_gather_returns(env.summary()[:, 0].contiguous(), async_op=True))
-        counts.append(steps)
-    for _, work in pending:
-        if work is not None:
-            work.wait()
+        pending.append(one_pass(k, True))
+        if len(pending) > 1 and pending[-2] is not None and pending[-2][1] is not None:
+            pending[-2][1].wait()           # the buffer of pass k-1 is reused by pass k+1
+    for g in pending:
+        if g is not None and g[1] is not None:
+            g[1].wait()
     torch.cuda.synchronize(dev)
     ctx.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = ctx.max_over_ranks(elapsed)
-    local_steps = int(torch.stack(counts).sum().item())
+    local_steps = int(sum(int(torch.stack(sb.counts).sum().item()) for sb in subs))
     total_steps = ctx.sum_over_ranks(local_steps)
-    kern_s = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / 1e3
+    launch_ms = [a.elapsed_time(b) for sb in subs for a, b in sb.ev]
+    warm_steps = int(sum(int(torch.stack(sb.warm).sum().item()) for sb in subs if sb.warm))
 
-    flags = env.status()["flags"].cpu().numpy()
-    assert (flags & 0x38).sum() == 0, "env error flags set"
+    for sb in subs:
+        flags = sb.env.status()["flags"].cpu().numpy()
+        assert (flags & 0x38).sum() == 0, "env error flags set"
     if ctx.rank != 0:
         ctx.shutdown()
         return
 
+    step_s = elapsed / K
+    dec_per_step = local_steps / K
     Wb = algorithmic_bytes_per_step(A, T)
-    achieved = local_steps * Wb / kern_s / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            j = json.load(open(pmc))
-            if j.get("workload") == f"{B}x{A}A{T}T":
-                traffic = j.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    c = load_counters(f"k_rollout_random:{A}A{T}T")           # per-decision PMC averages measured by tools/profile.sh
+    roof = {"kernel": "k_rollout_random", "avg_launch_ms": float(np.mean(launch_ms)), "launches_per_step": S,
+            "decisions_per_step": dec_per_step}
+    if c:
+        # Issue-bound roofline: the persistent kernel keeps the record in LDS, so HBM is not what limits it (hbm.frac
+        # below); the binding resource is VALU issue.  SQ_ACTIVE_INST_VALU counts, per wave, the quad-cycles (4 clocks:
+        # one wave64 instruction on a 16-lane SIMD) the VALU spends executing that wave's instructions
+        # (profiles/r02_calib: == SQ_INSTS_VALU for fp64 FMA streams).  achieved = VALU-busy SIMD-cycles per second of
+        # this run, peak = 1024 SIMDs x 2.4 GHz.
+        valu_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU_per_decision"] * dec_per_step
+        achieved = valu_cycles / step_s / 1e9
+        peak = N_SIMD * PEAK_CLOCK_HZ / 1e9
+        traffic = c.get("hbm_bytes_per_decision")
+        traffic = traffic * dec_per_step if traffic is not None and not args.no_obs else None
+        roof.update({"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s (VALU busy)",
+                     "frac": achieved / peak,
+                     "lane_util": c["SQ_THREAD_CYCLES_VALU_per_decision"] / (64.0 * c["SQ_ACTIVE_INST_VALU_per_decision"]),
+                     "valu_insts_per_decision": c.get("SQ_INSTS_VALU_per_decision"),
+                     "salu_insts_per_decision": c.get("SQ_INSTS_SALU_per_decision"),
+                     "traffic": traffic,
+                     "hbm": {"achieved": (traffic / step_s / 1e9) if traffic else None, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                             "unit": "GB/s", "frac": (traffic / step_s / HBM_PEAK_BYTES_PER_S) if traffic else None,
+                             "note": "measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE) per pass / pass time"},
+                     "counters_source": c.get("source")})
+    else:
+        roof.update({"bound": "valu_issue", "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e9,
+                     "unit": "G SIMD-cycles/s (VALU busy)", "frac": None, "traffic": None,
+                     "note": f"no PMC profile committed for {A}A/{T}T (profiles/counters.json)"})
+    # SURVEY.md §8(d) prices a decision with W = 2S + O + 4 algorithmic bytes whatever the kernel really moves; for the
+    # LDS-resident kernel that figure is NOT a utilisation (it exceeds the HBM peak) and is reported only for the record
+    roof["w_scored"] = {"algorithmic_bytes_per_step": Wb, "equiv_GBps": dec_per_step * Wb / step_s / 1e9,
+                        "note": "SURVEY §8(d) pricing; the record never leaves LDS, see roofline.hbm for real traffic"}
     out = {
         "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": K,
-        "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": cfg["scaling"],
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{B} envs/GPU x {A}A/{T}T random-policy rollout, HIP env only (BASELINE configs[1])",
-                   "envs_per_gpu": B, "agents": A, "tasks": T, "episodes_per_step": args.episodes,
-                   "decisions_per_step_per_gpu": local_steps / K, "sharding": f"env batch x{ctx.world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                     "frac": achieved * 1e9 / HBM_PEAK_BYTES_PER_S, "traffic": traffic, "kernel": "k_rollout_random",
-                     "algorithmic_bytes_per_step": Wb, "avg_launch_ms": kern_s / K * 1e3},
+        "config": {"workload": (f"{B} envs/GPU x {A}A/{T}T random-policy rollout, HIP env only ({cfg['label']})"
+                                if cfg["scaling"] == "weak" else
+                                f"{n_total} envs x {A}A/{T}T random-policy rollout sharded over {ctx.world} GPU(s), HIP env only "
+                                f"({cfg['label']})"),
+                   "envs_per_gpu": B, "envs_total": n_total, "agents": A, "tasks": T, "episodes_per_step": EP,
+                   "decisions_per_step_per_gpu": dec_per_step, "decisions_in_warmup_per_gpu": warm_steps, "streams_per_gpu": S,
+                   "sharding": f"env batch x{ctx.world}, no data-path collective"
+                               + (", one async all-gather of the episode returns per pass" if ctx.active else ""),
+                   "dist_backend": ctx.backend or None},
+        "roofline": roof,
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(inst, seeds, A)
+        sb = subs[0]
+        inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
+        out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
     if ctx.world == 1 and not args.no_lockstep_probe:
+        for sb in subs:
+            sb.env.close()
         out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)
     print(json.dumps(out), flush=True)
     ctx.shutdown()

@@ -30,6 +30,9 @@ class DistContext:
 
     @classmethod
     def from_env(cls, expected_world=None, backend=None, device=None):
+        # before anything initialises HIP/HSA: the host driver of this pool only supports dmabuf IPC (without it RCCL fails
+        # with hipIpcGetMemHandle: invalid argument)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,9 +46,9 @@ class DistContext:
             idx = int(forced) if forced is not None else local
             device = torch.device("cuda", idx) if torch.cuda.is_available() else torch.device("cpu")
         be = ""
-        if world > 1:
+        # DCM_DIST_FORCE_INIT=1: initialise the process group even for one rank (exercises the RCCL branch on a 1-GPU box)
+        if world > 1 or os.environ.get("DCM_DIST_FORCE_INIT") == "1":
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             be = backend or os.environ.get("DCM_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
             if device.type == "cuda":
                 torch.cuda.set_device(device)
@@ -58,18 +61,37 @@ class DistContext:
         return torch.device("cpu") if self.backend == "gloo" else self.device
 
     def barrier(self):
-        if self.world > 1:
+        if self._active():
             dist.barrier()
 
-    def all_gather_returns(self, local_returns, async_op=False):
-        """local_returns [B_local] (any float dtype) -> [world*B_local] on every rank, rank-major order.
+    def _active(self):
+        return self.world > 1 or (dist.is_available() and dist.is_initialized())
+
+    @property
+    def active(self):
+        """True when a process group is up (N > 1, or one rank with DCM_DIST_FORCE_INIT=1): collectives really run."""
+        return self._active()
+
+    def all_gather_returns(self, local_returns, async_op=False, n_total=None):
+        """local_returns [B_local] (any float dtype) -> [n_total] on every rank, rank-major order (shard_range blocks).
         async_op=True returns (out, work): the collective runs on RCCL's stream and the caller's stream keeps
-        launching env kernels; call work.wait() before reading `out`."""
-        if self.world == 1:
+        launching env kernels; call work.wait() before reading `out`.  n_total: number of envs over all ranks when the
+        blocks are uneven (n_total % world != 0): the shorter blocks are padded for the collective and trimmed again."""
+        if not self._active():
             return (local_returns, None) if async_op else local_returns
         local_returns = local_returns.contiguous()
+        n_loc = local_returns.numel()
+        even = n_total is None or n_total == self.world * n_loc
+        if not even:
+            pad = -(-n_total // self.world)
+            buf = torch.zeros((pad,), dtype=local_returns.dtype, device=local_returns.device)
+            buf[:n_loc] = local_returns
+            full = self.all_gather_returns(buf)
+            sizes = [shard_range(n_total, r, self.world) for r in range(self.world)]
+            out = torch.cat([full[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+            return (out, None) if async_op else out
         if async_op and self.backend != "gloo":
-            out = torch.empty((self.world * local_returns.numel(),), dtype=local_returns.dtype, device=local_returns.device)
+            out = torch.empty((self.world * n_loc,), dtype=local_returns.dtype, device=local_returns.device)
             return out, dist.all_gather_into_tensor(out, local_returns, async_op=True)
         if async_op:
             return self.all_gather_returns(local_returns), None
@@ -77,25 +99,43 @@ class DistContext:
             parts = [torch.empty(local_returns.shape, dtype=local_returns.dtype) for _ in range(self.world)]
             dist.all_gather(parts, local_returns.cpu())
             return torch.cat(parts).to(local_returns.device)
-        out = torch.empty((self.world * local_returns.numel(),), dtype=local_returns.dtype, device=local_returns.device)
+        out = torch.empty((self.world * n_loc,), dtype=local_returns.dtype, device=local_returns.device)
         dist.all_gather_into_tensor(out, local_returns)
         return out
 
+    def verify_gather(self, gathered, local_returns, first):
+        """Raise unless `gathered` is the rank-major concatenation of every rank's local vector ON EVERY RANK: this rank's
+        block sits at [first, first + B_local) bit for bit, and all ranks hold the same vector (min == max over ranks of a
+        position-weighted checksum of the raw bits)."""
+        g = gathered.contiguous().view(torch.int64) if gathered.dtype == torch.float64 else gathered
+        l = local_returns.contiguous().view(torch.int64) if local_returns.dtype == torch.float64 else local_returns
+        if not torch.equal(g[first:first + l.numel()].cpu(), l.cpu()):
+            raise RuntimeError(f"rank {self.rank}: gathered returns do not hold this rank's block at offset {first}")
+        if self._active():
+            w = torch.arange(1, g.numel() + 1, dtype=torch.int64, device=g.device)
+            h = ((g.to(torch.int64) >> 12) * w).sum().to(torch.float64).reshape(1).to(self._coll_device())
+            lo, hi = h.clone(), h.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if float(lo) != float(hi):
+                raise RuntimeError("ranks hold different gathered return vectors")
+        return True
+
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if not self._active():
             return x
         t = torch.tensor([x], dtype=torch.float64, device=self._coll_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(self, x):
-        if self.world == 1:
+        if not self._active():
             return x
         t = torch.tensor([x], dtype=torch.int64, device=self._coll_device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
 
     def shutdown(self):
-        if self.world > 1 and dist.is_initialized():
+        if self._active():
             dist.barrier()
             dist.destroy_process_group()

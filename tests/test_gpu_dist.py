@@ -43,8 +43,49 @@ def test_single_gpu_bench_contract_line(gpu_device):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["dtype"] == "f64" and j["data"] == "synthetic" and j["higher_is_better"] is True
     assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["envs_per_gpu"] == 4096
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the persistent kernel is issue-bound: frac = VALU-busy SIMD-cycles / available SIMD-cycles, a utilisation (<= 1)
+    assert r["bound"] == "valu_issue" and r["kernel"] == "k_rollout_random" and r["peak"] == 1024 * 2.4
+    assert r["frac"] is not None and 0.05 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["lane_util"] <= 1.0 and r["counters_source"].startswith("profiles/")
     assert r["traffic"] is None or r["traffic"] > 0
+    assert r["hbm"]["frac"] is None or 0.0 < r["hbm"]["frac"] <= 1.0          # measured HBM bytes: far below the peak
+    assert r["w_scored"]["algorithmic_bytes_per_step"] == 13203
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "steps/s" and "sample" in c
+    assert c["at_8_threads"]["cores"] <= 8 and c["at_8_threads"]["value"] > 0   # mirror of NUM_META_AGENT = 8 (runner.py:74)
     assert j["value"] > 1e6          # the north-star floor (1M env-steps/s on one MI355X)
+
+
+def test_rccl_branch_runs_on_one_rank(gpu_device):
+    """The RCCL ("nccl") branch of dcmrta_amd/dist.py on real hardware: a one-rank process group (DCM_DIST_FORCE_INIT=1)
+    makes bench.py take exactly the N > 1 code path -- init_process_group("nccl", device_id=...), the asynchronous
+    all_gather_into_tensor of the episode returns racing the next pass, work.wait() ordering, the gathered-vector
+    verification, the barrier and the max / sum reductions over ranks."""
+    env = dict(os.environ, DCM_DIST_FORCE_INIT="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29573")
+    env.pop("DCM_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--envs", "1024", "--no-cpu-baseline", "--no-lockstep-probe"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["config"]["dist_backend"] == "nccl" and "all-gather" in j["config"]["sharding"]
+    assert j["n_gpus"] == 1 and j["value"] > 1e6
+
+
+def test_config4_strong_scaling_line(gpu_device):
+    """bench.py --config 4 (BASELINE configs[3]: 65 536 envs x 50A/200T sharded over the ranks, strong scaling), here two
+    ranks on the one GPU over gloo with a reduced env count: contiguous shards, gathered returns verified on every rank."""
+    env = dict(os.environ, DCM_FORCE_DEVICE="0", DCM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29575", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "2", "--warmup", "1",
+           "--envs", "1001"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["agents"] == 50 and j["config"]["tasks"] == 200
+    assert j["config"]["envs_total"] == 1001 and j["config"]["envs_per_gpu"] == 501      # uneven shards: 501 + 500
+    per_pass = j["value"] * j["ms_per_step"] / 1e3
+    assert 1001 * 200 < per_pass < 1001 * 500                                             # ~320 decisions per episode
