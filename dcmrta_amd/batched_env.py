@@ -68,6 +68,10 @@ class BatchedTaskEnv:
         self._leader = torch.empty((B,), dtype=torch.int32, device=dev)
         self._active = torch.empty((B,), dtype=torch.uint8, device=dev)
         self._instances = None
+        self.n_agents = self.n_tasks = None
+        # bumped whenever something a captured HIP graph of dcm_step has baked in changes (raggedness of the batch: the
+        # per-env sizes pointer and the kernel instantiation; the route-log pointers): GraphedRollout re-captures
+        self.graph_epoch = 0
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -116,6 +120,8 @@ class BatchedTaskEnv:
         du = self._dev(dur, torch.float64)
         if d.shape != (B, 2) or xy.shape != (B, T, 2) or du.shape != (B, T):
             raise DcmError("instance arrays have the wrong shape")
+        if (n_tasks is None) != (self.n_tasks is None):
+            self.graph_epoch += 1
         with torch.cuda.device(self.device):
             if n_tasks is None:
                 check(self._lib.dcm_load_instances(self._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du), self._stream()))
@@ -238,6 +244,13 @@ class BatchedTaskEnv:
             check(self._lib.dcm_get_members(self._h, _ptr(out), self._stream()))
         return out
 
+    def abandoned_counts(self):
+        """int16[B,A,T]: how often task t has moved agent a to its abandoned_agent list this episode (env/task_env.py:89)."""
+        out = torch.empty((self.B, self.A, self.T), dtype=torch.int16, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_get_abandoned(self._h, _ptr(out), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ route history (agent['route'], agent['arrival_time'])
     def enable_route_log(self, cap=64):
         """Record every agent_step of the lockstep API (reset / step): route_task[B,A,cap] (-1 = depot), route_arrival, route_len."""
@@ -246,6 +259,7 @@ class BatchedTaskEnv:
                        torch.zeros((B, A, cap), dtype=torch.float64, device=dev),
                        torch.zeros((B, A), dtype=torch.int32, device=dev))
         check(self._lib.dcm_set_route_log(self._h, *[_ptr(x) for x in self._route], int(cap)))
+        self.graph_epoch += 1
         return self
 
     def routes(self):

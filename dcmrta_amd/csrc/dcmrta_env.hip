@@ -1200,6 +1200,29 @@ __global__ void k_get_members(int T, int PA, int PT, const unsigned char* state,
     for (int j = 0; j < M; j++) ids_out[i * M + j] = (j < n) ? (int16_t)((ids >> (8 * j)) & 0xFF) : (int16_t)-1;
 }
 
+// task['abandoned_agent'] (env/task_env.py:89) as a dense count table: out[B][A][T] = number of times task t moved agent a to
+// its abandoned_agent list in the current episode = entries of the agent's abandonment log + the overflow count table
+__global__ __launch_bounds__(WAVE) void k_get_abandoned(int A, int T, int PA, int PT, const unsigned char* state,
+                                                       const uint16_t* ablog, uint16_t* out, const int32_t* sizes) {
+    const int e = blockIdx.x, lane = threadIdx.x, B = gridDim.x;
+    int eA, eT;
+    env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
+    const Lay L{PA, PT};
+    const uint32_t* ainfo = (const uint32_t*)(state + (size_t)e * L.rec_bytes() + L.ainfo());
+    const uint16_t* log_e = ablog + (size_t)e * A * AB_CAP;
+    const uint16_t* cnt_e = (const uint16_t*)((const uint8_t*)(ablog + (size_t)B * A * AB_CAP) + (size_t)e * abcnt_pitch(A, T));
+    uint16_t* o = out + (size_t)e * A * T;
+    for (int i = lane; i < A * T; i += WAVE) o[i] = 0;
+    __syncthreads();
+    for (int a = lane; a < eA; a += WAVE) {                                 // one lane per agent: no two lanes share a row
+        const uint32_t nab = ainfo[a] >> 16;
+        const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+        for (int i = 0; i < nl; i++) o[a * T + log_e[a * AB_CAP + i]] += 1;
+        if (nab > (uint32_t)AB_CAP)
+            for (int t = 0; t < eT; t++) o[a * T + t] += cnt_e[a * eT + t];
+    }
+}
+
 __global__ void k_distance(const double* ax, const double* ay, const double* bx, const double* by, double* dist_out,
                            double* time_out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1461,6 +1484,15 @@ int dcm_get_members(dcm_env* env, int16_t* ids_out, void* stream) {
     const int64_t n = (int64_t)env->p.n_envs * env->T;
     hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->T, env->L.A, env->L.T,
                        env->state, env->p.n_envs, ids_out, (const int32_t*)env->sizes);
+    LAUNCH_OK();
+    return DCM_OK;
+}
+
+int dcm_get_abandoned(dcm_env* env, uint16_t* counts_out, void* stream) {
+    CHECK_ENV(env);
+    if (!counts_out) return fail(DCM_ERR_INVALID, "dcm_get_abandoned: null counts_out");
+    hipLaunchKernelGGL(k_get_abandoned, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, env->ablog, counts_out,
+                       (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
 }

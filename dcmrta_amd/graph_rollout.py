@@ -1,25 +1,54 @@
 """HIP-graph capture of the policy-in-the-loop step.
 
-One decision of the batched loop -- policy forward on the observation tensors, action selection, dcm_step with the
-fused observation of the next decision (worker.py:62-76) -- is a fixed sequence of kernels on fixed buffers, so it is
-captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed: no per-kernel launch cost, no host work
-between the policy and the env.  The host only looks at `active` every `check_every` replays to detect the end of the
-batch of episodes (steps on finished envs are no-ops on the device).  The policy itself stays stock PyTorch.
+One decision of the batched loop -- policy forward on the observation tensors, action selection, the experience record,
+dcm_step with the fused observation of the next decision (worker.py:62-83) -- is a fixed sequence of kernels on fixed
+buffers, so it is captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed: no per-kernel launch cost,
+no host work between the policy and the env, no host sync per decision.  The host only looks at `active` every
+`check_every` replays to detect the end of the batch of episodes (steps on finished envs are no-ops on the device).
+The policy itself stays stock PyTorch.
+
+Experience (worker.py:77-83) is written inside the graph with one indexed store per field into [capacity, B, ...]
+buffers at a device-side step counter, so recording needs no host involvement either.
 """
 import torch
 
 
 class GraphedRollout:
-    def __init__(self, env, policy, check_every=8, warmup=3):
-        """policy(obs) -> int32/int64 actions[B] computed with torch ops on env.device (no host syncs, no new
-        persistent allocations); it is captured together with env.step."""
+    def __init__(self, env, policy, check_every=8, warmup=3, record=False, capacity=None):
+        """policy(obs) -> integer actions[B] computed with torch ops on env.device (no host syncs, no new persistent
+        allocations); it is captured together with env.step.  record=True keeps what worker.py:77-83 appends per decision
+        (agent / task observation, action, mask, deciding agent, plus the `active` flag of the env) for up to `capacity`
+        batched steps."""
         self.env, self.policy, self.check_every = env, policy, int(check_every)
-        self.action = torch.zeros((env.B,), dtype=torch.int32, device=env.device)
+        B, A, T, dev = env.B, env.A, env.T, env.device
+        self.action = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.graph = None
         self._warmup = warmup
+        self._epoch = None
+        self.capacity = int(capacity) if capacity is not None else 6 * (A + T) + 64
+        self.rec = None
+        if record:
+            S = self.capacity
+            self.rec = dict(agents=torch.empty((S, B, A, 6), dtype=torch.float32, device=dev),
+                            tasks=torch.empty((S, B, T + 1, 5), dtype=torch.float32, device=dev),
+                            mask=torch.empty((S, B, T + 1), dtype=torch.bool, device=dev),
+                            action=torch.zeros((S, B), dtype=torch.int64, device=dev),
+                            leader=torch.zeros((S, B), dtype=torch.int64, device=dev),
+                            active=torch.zeros((S, B), dtype=torch.bool, device=dev))
+            self.slot = torch.zeros((1,), dtype=torch.int64, device=dev)      # device-side step counter
 
     def _one_step(self, obs):
-        self.action.copy_(self.policy(obs).to(torch.int32))
+        a = self.policy(obs)
+        self.action.copy_(a)
+        if self.rec is not None:
+            r, i = self.rec, self.slot
+            r["agents"].index_copy_(0, i, obs.agents.unsqueeze(0))
+            r["tasks"].index_copy_(0, i, obs.tasks.unsqueeze(0))
+            r["mask"].index_copy_(0, i, obs.mask.unsqueeze(0))
+            r["action"].index_copy_(0, i, a.to(torch.int64).unsqueeze(0))
+            r["leader"].index_copy_(0, i, obs.leader.to(torch.int64).unsqueeze(0))
+            r["active"].index_copy_(0, i, obs.active.unsqueeze(0))
+            self.slot.add_(1).clamp_(max=self.capacity - 1)
         return self.env.step(self.action)
 
     def capture(self, seeds):
@@ -35,20 +64,33 @@ class GraphedRollout:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._one_step(obs)
+        # the captured dcm_step bakes in the handle's kernel arguments (per-env sizes pointer, route-log pointers, shape
+        # instantiation): a later change of any of them must re-capture
+        self._epoch = env.graph_epoch
         return self
 
     @torch.no_grad()
-    def run(self, seeds, max_steps=100000):
-        """Play one episode per env; returns (summary[B,8], batched_steps)."""
+    def run(self, seeds, max_steps=None):
+        """Play one episode per env; returns (summary[B,8], batched_steps).  With record=True the experience of batched
+        step s is self.rec[...][s] (valid where rec["active"][s])."""
         env = self.env
-        if self.graph is None:
+        if self.graph is None or self._epoch != env.graph_epoch:
             self.capture(seeds)
         obs = env.reset(seeds)
+        if self.rec is not None:
+            self.slot.zero_()
+        limit = max_steps if max_steps is not None else (self.capacity if self.rec is not None else 1 << 30)
         n = 0
-        while n < max_steps:
+        while True:
             for _ in range(self.check_every):
                 self.graph.replay()
             n += self.check_every
-            if not bool(obs.active.any()):        # obs tensors are the env's static output buffers
+            if not bool(obs.active.any()):        # obs tensors are the env's static output buffers; one sync per check
                 break
+            if n >= limit:
+                raise RuntimeError(f"episodes still running after {n} batched steps (capacity / max_steps {limit}): "
+                                   f"raise `capacity`")
+        if self.rec is not None and n > self.capacity:
+            raise RuntimeError(f"{n} batched steps recorded into {self.capacity} slots: raise `capacity`")
+        self.steps = n
         return env.summary(), n

@@ -7,106 +7,189 @@ advantage (worker.py:91-101, GAMMA=1 so every decision of an episode carries the
 perf metrics (worker.py:103-108).  The env work is the HIP path (BatchedTaskEnv); the policy is whatever module the
 caller supplies (`net_factory`, e.g. the reference's own AttentionNet) -- by default the stand-in of dcmrta_amd.policy.
 
+Every rollout is one captured HIP graph per decision (policy forward -> action -> experience store -> dcm_step with the
+fused observation of the next decision; dcmrta_amd/graph_rollout.py) replayed without a host sync per decision: the host
+looks at the `active` flags once every `check_every` batched steps.
+
 job() keeps the reference signature and return shape:
     jobResults : list of 9 sequences; torch.stack(jobResults[k]) gives (N,A,6), (N,T+1,5), (N,1) int64, (N,T+1) bool,
                  (N,1), (N,1,1) int64, (N,1) -- N = decisions of all B episodes, episode-major order
     metrics    : dict with success_rate, makespan, time_cost, waiting_time, travel_dist, efficiency (means over the batch)
     info       : {"id", "episode_number"}
 """
+import collections
+
 import numpy as np
 import torch
 
+from . import _lib
 from .batched_env import BatchedTaskEnv
 from .choice import env_seeds
+from .graph_rollout import GraphedRollout
 from .instances import generate_batch, generate_batch_ranges
 
 METRIC_KEYS = ("success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency")
+_PRECISIONS = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+class EnvError(RuntimeError):
+    """An env of the batch was frozen by the device (bad action / member overflow / bad leader): its results are undefined."""
 
 
 class BatchedRunner:
-    def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=1024, gamma=1.0):
+    def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
+                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8):
+        """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
+        of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
+        rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
+        steps (default 6 (A + T) + 64, ~3x the longest episode seen at the reference's constants)."""
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
         self.base_seed = int(base_seed)
-        self.max_steps = int(max_steps)
+        self.max_steps = None if max_steps is None else int(max_steps)
         self.gamma = float(gamma)            # GAMMA, parameters.py:6 (1 in the reference)
+        self.check_every, self.use_graph = int(check_every), bool(use_graph)
         if net_factory is None:
             from .policy import AttentionNet
             net_factory = lambda: AttentionNet(6, 5, 128)  # AGENT_INPUT_DIM, TASK_INPUT_DIM, EMBEDDING_DIM (parameters.py:29-31)
         self.localNetwork = net_factory().to(self.device)     # runner.py:18-19
         self.localBaseline = net_factory().to(self.device)    # runner.py:20-21
+        if rollout_precision not in _PRECISIONS:
+            raise ValueError(f"rollout_precision must be one of {sorted(_PRECISIONS)}")
+        self.rollout_precision = rollout_precision
+        self._shadow = None
+        if _PRECISIONS[rollout_precision] is not None:
+            if not hasattr(self.localNetwork, "rollout_copy"):
+                raise ValueError("rollout_precision != 'fp32' needs a net with rollout_copy() / sync_rollout_copy()")
+            self._shadow = self.localNetwork.rollout_copy(_PRECISIONS[rollout_precision])
+        self._cache = collections.OrderedDict()   # (A, T, individual_selection) -> {"env", "graphs"}
+        self._cache_shapes = int(cache_shapes)
         self._env = None
         self.timing = {}
+        self.last = {}
 
     # ------------------------------------------------------------------ weights (runner.py:23-30)
     def get_weights(self):
         return self.localNetwork.state_dict()
 
     def set_weights(self, weights):
-        self.localNetwork.load_state_dict(weights)
+        self.localNetwork.load_state_dict(weights)          # in place: captured graphs keep reading the same tensors
+        if self._shadow is not None:
+            self.localNetwork.sync_rollout_copy(self._shadow)
 
     def set_baseline_weights(self, weights):
         self.localBaseline.load_state_dict(weights)
 
+    def _rollout_net(self):
+        return self._shadow if self._shadow is not None else self.localNetwork
+
     # ------------------------------------------------------------------ env management
+    def _slot(self, A, T, individual_selection=False, n_envs=None):
+        """Env + captured graphs of one batch shape.  Training draws a new (agents_num, tasks_num) every round
+        (driver.py:114-115), so the last few shapes are kept."""
+        key = (A, T, bool(individual_selection), int(n_envs or self.B))
+        slot = self._cache.get(key)
+        if slot is None:
+            slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection),
+                        graphs={})
+            self._cache[key] = slot
+            while len(self._cache) > self._cache_shapes:
+                _, old = self._cache.popitem(last=False)
+                old["graphs"].clear()
+                old["env"].close()
+        else:
+            self._cache.move_to_end(key)
+        self._env = slot["env"]
+        return slot
+
     def _get_env(self, A, T):
-        if self._env is None or (self._env.A, self._env.T) != (A, T):
-            if self._env is not None:
-                self._env.close()
-            self._env = BatchedTaskEnv(self.B, A, T, device=str(self.device))
-        return self._env
+        return self._slot(A, T)["env"]
 
     # ------------------------------------------------------------------ one batched episode (worker.py:45-87)
-    @torch.no_grad()
-    def rollout(self, net, env, seeds, greedy, record):
-        B, A, T, dev = env.B, env.A, env.T, env.device
-        obs = env.reset(seeds)
-        S, CH = self.max_steps, 128
-        chunks = []                       # experience is recorded in chunks of CH batched steps, allocated on demand
+    @staticmethod
+    def _select(mode):
+        if mode == "sample":      # worker.py:70: Categorical(logp.exp()).sample()
+            return lambda logp, mask: torch.multinomial(logp.exp(), 1).squeeze(1)
+        if mode == "greedy":      # worker.py:228
+            return lambda logp, mask: torch.argmax(logp, dim=1)
+        if mode == "test":        # worker.py:140 / :185
+            return lambda logp, mask: torch.argmax(logp.exp() * ~mask, dim=1)
+        raise ValueError(mode)
 
-        def new_chunk():
-            return dict(agents=torch.empty((CH, B, A, 6), dtype=torch.float32, device=dev),
-                        tasks=torch.empty((CH, B, T + 1, 5), dtype=torch.float32, device=dev),
-                        mask=torch.empty((CH, B, T + 1), dtype=torch.bool, device=dev),
-                        action=torch.zeros((CH, B), dtype=torch.int64, device=dev),
-                        leader=torch.zeros((CH, B), dtype=torch.int64, device=dev),
-                        active=torch.zeros((CH, B), dtype=torch.bool, device=dev))
+    def _check_flags(self, env, what):
+        """The device freezes an env whose action is masked / out of range (BAD_ACTION), would overfill a task (OVERFLOW)
+        or whose injected leader is not deciding (BAD_LEADER) and never computes its terminal row: refuse to average NaN
+        rewards into the batch (the reference would step onto the masked task; its policy contract never does,
+        attention.py:74-76).  Truncated episodes (zero-decider guard) are counted and reported."""
+        flags = env.status()["flags"]
+        bad = (flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER)) != 0
+        n_bad = int(bad.sum())
+        if n_bad:
+            first = int(torch.nonzero(bad)[0])
+            raise EnvError(f"{what}: {n_bad} of {env.B} envs were frozen by the device (first: env {first}, flags "
+                           f"{int(flags[first]):#x}): the policy chose a masked / out-of-range action or a task overflowed; "
+                           f"check that the net puts probability 0 on masked actions (attention.py:74-76)")
+        return int(((flags & _lib.FLAG_TRUNCATED) != 0).sum())
+
+    @torch.no_grad()
+    def rollout(self, net, slot, seeds, mode, record):
+        """One episode per env under `net`; mode "sample" | "greedy" | "test".  Returns (summary[B,8], rec, n_steps):
+        rec = dict of [n_steps, B, ...] experience tensors (views of the graph's static buffers: consume them before the
+        next recorded rollout of the same shape) or None."""
+        env = slot["env"]
+        select = self._select(mode)
+
+        def policy(obs):
+            return select(net(obs.tasks, obs.agents, obs.mask), obs.mask)
+        if not self.use_graph:
+            return self._rollout_eager(policy, env, seeds, record)
+        key = (id(net), mode, bool(record))
+        g = slot["graphs"].get(key)
+        if g is None:
+            g = GraphedRollout(env, policy, check_every=self.check_every, record=record, capacity=self.max_steps)
+            slot["graphs"][key] = g
+        summary, n = g.run(seeds)
+        rec = {k: v[:n] for k, v in g.rec.items()} if record else None
+        return summary, rec, n
+
+    def _rollout_eager(self, policy, env, seeds, record):
+        """The same loop as plain launches with a host sync per decision (debugging / comparison)."""
+        obs = env.reset(seeds)
+        cap = self.max_steps if self.max_steps is not None else 6 * (env.A + env.T) + 64
+        rec = [] if record else None
         s = 0
-        while True:
-            if not bool(obs.active.any()):       # worker.py:45 for every env of the batch
-                break
-            if s >= S:
+        while bool(obs.active.any()):
+            if s >= cap:
                 raise RuntimeError("episode longer than max_steps")
-            logp = net(obs.tasks, obs.agents, obs.mask)                          # worker.py:69
-            if greedy:
-                action = torch.argmax(logp, dim=1)                               # worker.py:228
-            else:
-                action = torch.distributions.Categorical(logits=logp).sample()  # worker.py:70 (probs = logp.exp())
+            action = policy(obs)
             if record:
-                if s % CH == 0:
-                    chunks.append(new_chunk())
-                c, i = chunks[-1], s % CH
-                c["agents"][i].copy_(obs.agents); c["tasks"][i].copy_(obs.tasks); c["mask"][i].copy_(obs.mask)
-                c["action"][i].copy_(action); c["leader"][i].copy_(obs.leader); c["active"][i].copy_(obs.active)
-            obs = env.step(action.to(torch.int32))                               # worker.py:73-76,85
+                rec.append(dict(agents=obs.agents.clone(), tasks=obs.tasks.clone(), mask=obs.mask.clone(),
+                                action=action.to(torch.int64), leader=obs.leader.to(torch.int64), active=obs.active.clone()))
+            obs = env.step(action.to(torch.int32))
             s += 1
-        rec = None
-        if record:
-            rec = {k: torch.cat([c[k] for c in chunks])[:max(s, 1)] for k in chunks[0]} if chunks else None
-        summary = env.summary()                                                  # worker.py:87,103-108
-        return summary, rec, s
+        out = {k: torch.stack([r[k] for r in rec]) for k in rec[0]} if rec else None
+        return env.summary(), out, s
 
     def _experience(self, rec, n_steps, reward, advantage, as_lists):
         """9-slot buffer of worker.py:42,77-83,91-101 for all episodes, episode-major."""
+        B = reward.shape[0]
+        if rec is None or n_steps == 0:       # no env took a decision
+            A, T = self._env.A, self._env.T
+            dev = reward.device
+            e = lambda *shape, dtype=torch.float32: torch.empty((0,) + shape, dtype=dtype, device=dev)
+            slots = [e(A, 6), e(T + 1, 5), e(1, dtype=torch.int64), e(T + 1, dtype=torch.bool), e(1), e(1, 1, dtype=torch.int64),
+                     e(1), [], []]
+            return [list(x.unbind(0)) if (as_lists and isinstance(x, torch.Tensor)) else x for x in slots]
         act = rec["active"][:n_steps].t()                                        # [B,S]
+
         def pick(x):
             return x[:n_steps].transpose(0, 1)[act]                              # [N,...] env-major, step order
         agents, tasks, mask = pick(rec["agents"]), pick(rec["tasks"]), pick(rec["mask"])
         action = pick(rec["action"]).unsqueeze(1)                                # (N,1) int64, slot 2
         agent_id = pick(rec["leader"]).view(-1, 1, 1)                            # (N,1,1) int64, slot 5
         counts = act.sum(1)                                                      # decisions per episode
-        env_of = torch.repeat_interleave(torch.arange(act.shape[0], device=act.device), counts)
+        env_of = torch.repeat_interleave(torch.arange(B, device=act.device), counts)
         last = torch.cumsum(counts, 0) - 1
         rew = torch.zeros((agents.shape[0], 1), dtype=torch.float32, device=agents.device)
         rew[last[counts > 0], 0] = reward[counts > 0].to(torch.float32)          # slot 4: 0 except the last decision (:81,:91)
@@ -134,26 +217,42 @@ class BatchedRunner:
         self.set_baseline_weights(baseline_weights)
         A = int(agents_num[1] if isinstance(agents_num, (tuple, list)) else agents_num)
         T = int(tasks_num[1] if isinstance(tasks_num, (tuple, list)) else tasks_num)
-        env = self._get_env(A, T)
+        slot = self._slot(A, T)
+        env = slot["env"]
         first = int(episodeNumber) * self.B
-        if self._is_range(agents_num) or self._is_range(tasks_num):
+        ragged = self._is_range(agents_num) or self._is_range(tasks_num)
+        if ragged:
             inst = generate_batch_ranges(range(self.base_seed + first, self.base_seed + first + self.B),
                                          tuple(agents_num) if isinstance(agents_num, (tuple, list)) else int(agents_num),
                                          tuple(tasks_num) if isinstance(tasks_num, (tuple, list)) else int(tasks_num))
         else:
             inst = generate_batch(self.B, A, T, base_seed=self.base_seed, first=first)   # worker.py:32
         env.load_instances(**inst)
+        net = self._rollout_net()
+        self._set_padding_hint(net, ragged)
         seeds = env_seeds(self.base_seed, first, self.B)
-        summary, rec, n_steps = self.rollout(self.localNetwork, env, seeds, greedy=False, record=True)   # run_episode
-        greedy_summary, _, _ = self.rollout(self.localNetwork, env, seeds, greedy=True, record=False)    # baseline_test :89
+        summary, rec, n_steps = self.rollout(net, slot, seeds, "sample", record=True)             # run_episode
+        truncated = self._check_flags(env, "sampled rollout")
+        greedy_summary, grec, g_steps = self.rollout(net, slot, seeds, "greedy", record=self.keep_greedy_record)  # baseline_test :89
+        truncated += self._check_flags(env, "greedy baseline rollout")
         reward, greedy_reward = summary[:, 0], greedy_summary[:, 0]
         advantage = reward - greedy_reward                                         # worker.py:92
         jobResults = self._experience(rec, n_steps, reward, advantage, as_lists)
         m = summary[:, 2:8].mean(0).cpu().numpy()
         metrics = {k: float(m[i]) for i, k in enumerate(METRIC_KEYS)}
         info = {"id": self.metaAgentID, "episode_number": episodeNumber}
-        self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps)
+        if truncated:
+            info["truncated_episodes"] = truncated
+        self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps, greedy_steps=g_steps,
+                         greedy_rec=grec, truncated=truncated)
         return jobResults, metrics, info
+
+    keep_greedy_record = False    # tests set it to replay the greedy twin through the oracle
+
+    @staticmethod
+    def _set_padding_hint(net, ragged):
+        if hasattr(net, "assume_no_padding"):
+            net.assume_no_padding = not ragged
 
     # ------------------------------------------------------------------ Worker.run_test / run_test_IS (worker.py:114-198)
     @torch.no_grad()
@@ -162,25 +261,24 @@ class BatchedRunner:
 
         instances: the load_instances keyword dict (depot[N,2], task_xy[N,T,2], req[N,T], dur[N,T], optionally n_agents /
         n_tasks for a ragged set) -- e.g. instances.load_instances_npz or instances.batch_from_dicts of unpickled test-set
-        envs.  Action = argmax(logp.exp() * ~mask) (worker.py:140,185).  individual_selection=True is run_test_IS: the
-        deciders of an event act one by one in ascending id without grouping.  Returns {metric: float64[N]} with the
-        six keys of worker.py:146-151 plus "reward"."""
+        envs.  n_agents: agents per env (required unless the dict carries its own per-env `n_agents`).  Action =
+        argmax(logp.exp() * ~mask) (worker.py:140,185).  individual_selection=True is run_test_IS: the deciders of an event
+        act one by one in ascending id without grouping.  Returns {metric: float64[N]} with the six keys of
+        worker.py:146-151 plus "reward"."""
         N, T = instances["req"].shape
-        A = int(n_agents if n_agents is not None else (instances["n_agents"].max() if "n_agents" in instances else self._env.A))
+        if n_agents is None and "n_agents" not in instances:
+            raise ValueError("run_test: give n_agents (agents per env) or a per-env `n_agents` array in `instances`")
+        A = int(n_agents if n_agents is not None else np.max(instances["n_agents"]))
         ss = env_seeds(self.base_seed, 0, N) if seeds is None else np.asarray(seeds, dtype=np.uint64)
-        env = BatchedTaskEnv(N, A, T, device=str(self.device), individual_selection=individual_selection)
+        slot = self._slot(A, T, individual_selection=individual_selection, n_envs=N)
+        env = slot["env"]
         env.load_instances(**instances)
-        obs = env.reset(ss)
-        for _ in range(self.max_steps * 4):
-            if not bool(obs.active.any()):
-                break
-            logp = self.localNetwork(obs.tasks, obs.agents, obs.mask)
-            action = torch.argmax(logp.exp() * ~obs.mask, dim=1)            # worker.py:140 / :185
-            obs = env.step(action.to(torch.int32))
-        else:
-            raise RuntimeError("run_test did not terminate")
-        sm = env.summary().cpu().numpy()
-        env.close()
+        net = self._rollout_net()
+        self._set_padding_hint(net, "n_agents" in instances)
+        sm, rec, n = self.rollout(net, slot, ss, "test", record=self.keep_greedy_record)
+        trunc = self._check_flags(env, "run_test")
+        self.last = dict(summary=sm, n_steps=n, rec=rec, truncated=trunc)
+        sm = sm.cpu().numpy()
         out = {k: sm[:, 2 + i].copy() for i, k in enumerate(METRIC_KEYS)}
         out["reward"] = sm[:, 0].copy()
         return out
@@ -197,15 +295,26 @@ class BatchedRunner:
         tr = tuple(tasks_range) if isinstance(tasks_range, (tuple, list)) else int(tasks_range)
         ss = [seed if seed is not None else 0] if seeds is None else list(seeds)
         out = []
-        env = self._get_env(A, T)
+        slot = self._slot(A, T)
+        env = slot["env"]
+        net = self._rollout_net()
+        ragged = self._is_range(ar) or self._is_range(tr)
+        self._set_padding_hint(net, ragged)
         for i in range(0, len(ss), self.B):
             chunk = ss[i:i + self.B]
             pad = chunk + [chunk[-1]] * (self.B - len(chunk))
             inst = generate_batch_ranges(pad, ar, tr)      # same draw order as TaskEnv(ar, tr, seed=s), sizes first
-            if not (self._is_range(ar) or self._is_range(tr)):
+            if not ragged:
                 inst.pop("n_agents"); inst.pop("n_tasks")  # uniform batch: shape-specialised kernels
             env.load_instances(**inst)
             cs = np.array([env_seeds(self.base_seed, int(s), 1)[0] for s in pad], dtype=np.uint64)
-            summary, _, _ = self.rollout(self.localNetwork, env, cs, greedy=True, record=False)
+            summary, _, _ = self.rollout(net, slot, cs, "greedy", record=False)
+            self._check_flags(env, "testing")
             out.extend(summary[:len(chunk), 0].cpu().numpy().tolist())
         return out[0] if seeds is None else np.array(out)
+
+    def close(self):
+        for slot in self._cache.values():
+            slot["graphs"].clear()
+            slot["env"].close()
+        self._cache.clear()

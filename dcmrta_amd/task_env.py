@@ -30,6 +30,8 @@ from .instances import generate_instance
 
 
 class TaskEnv:
+    _ROUTE_CAP = 256     # route entries kept per agent (the reference's lists are unbounded; max seen at its constants: 14)
+
     def __init__(self, agents_range=(10, 10), tasks_range=(10, 10), traits_dim=1, max_coalition_size=3, max_duration=5,
                  seed=None, plot_figure=False, device="cuda:0", choice_seed=0, individual_selection=False):
         if traits_dim != 1:
@@ -63,6 +65,7 @@ class TaskEnv:
         self._env = BatchedTaskEnv(1, A, self.tasks_num, device=device, max_waiting_time=self.max_waiting_time,
                                    individual_selection=individual_selection)
         self._env.load_instances(depot[None], task_xy[None], req[None], dur[None])
+        self._env.enable_route_log(cap=self._ROUTE_CAP)         # agent['route'] / agent['arrival_time'] (:95-96,314,318)
         self._seed = np.array([choice_seed], dtype=np.uint64)
         self._preset = [None] * A                      # agent['pre_set_route'], :595-599
         self._replay_summary = None
@@ -108,6 +111,14 @@ class TaskEnv:
         self._ag, self._tk = ag, tk
         obs = self._env.observe()
         self._leader_dev = int(obs.leader[0])
+        rt, ra, rl = (x[0].cpu().numpy() for x in self._env.routes())
+        if (rl > self._ROUTE_CAP).any():
+            raise RuntimeError(f"an agent's route has more than {self._ROUTE_CAP} entries (TaskEnv._ROUTE_CAP)")
+        self._routes = [(rt[a, :rl[a]].astype(np.int64).tolist(), ra[a, :rl[a]].tolist()) for a in range(self.agents_num)]
+        mem = self._env.task_members()[0].cpu().numpy()
+        self._members = [[int(m) for m in mem[t] if m >= 0] for t in range(self.tasks_num)]
+        ab = self._env.abandoned_counts()[0].cpu().numpy()
+        self._abandoned = [[a for a in range(self.agents_num) for _ in range(int(ab[a, t]))] for t in range(self.tasks_num)]
         if self._flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER):
             raise RuntimeError(f"env error flags {self._flags:#x}")
         if self._flags & _lib.FLAG_TRUNCATED:
@@ -134,10 +145,14 @@ class TaskEnv:
     def agent_dic(self):
         self._sync()
         a = self._ag
+        # route / arrival_time: the agent's visiting history (task ids, -1 = depot) and the arrival time of every entry
+        # (env/task_env.py:95-96, appended by agent_step :314,:318; read by worker.py:244-251 and generate_traj :375-418)
         return {i: {"ID": i, "location": np.array([a["x"][i], a["y"][i]]), "returned": bool(a["returned"][i]),
                     "assigned": bool(a["assigned"][i]), "next_decision": float(a["next_decision"][i]),
                     "travel_dist": float(a["travel_dist"][i]), "sum_waiting_time": float(a["sum_waiting_time"][i]),
-                    "velocity": 0.2, "depot": self.depot["location"]} for i in range(self.agents_num)}
+                    "route": list(self._routes[i][0]), "arrival_time": list(self._routes[i][1]),
+                    "pre_set_route": self._preset[i], "velocity": 0.2, "depot": self.depot["location"]}
+                for i in range(self.agents_num)}
 
     @property
     def task_dic(self):
@@ -148,6 +163,10 @@ class TaskEnv:
                     "feasible_assignment": bool(t["feasible"][i]), "finished": bool(t["finished"][i]),
                     "time_start": float(t["time_start"][i]), "time_finish": float(t["time_finish"][i]),
                     "status": np.array([int(t["status"][i])]), "sum_waiting_time": float(t["sum_waiting_time"][i]),
+                    # members: ordered list of agent ids (:78); abandoned_agent: every agent the task gave up on, once per
+                    # abandonment (:89; grouped by ascending agent id here -- the reference appends in event order, and
+                    # only membership / multiplicity are ever read, :357,:363)
+                    "members": list(self._members[i]), "abandoned_agent": list(self._abandoned[i]),
                     "n_members": int(t["n_members"][i]), "n_abandoned": int(t["n_abandoned"][i])}
                 for i in range(self.tasks_num)}
 
@@ -275,6 +294,10 @@ class TaskEnv:
         self._tk = dict(feasible=fin.copy(), finished=fin, time_start=g("time_start"), time_finish=g("time_finish"),
                         status=np.zeros(T, np.int32), sum_waiting_time=g("task_wait"), n_members=g("n_members"),
                         n_abandoned=np.zeros(T, np.int32))
+        # (the replay kernel keeps no visiting history / member lists: these views are empty after execute_by_route)
+        self._routes = [([], []) for _ in range(A)]
+        self._members = [[] for _ in range(T)]
+        self._abandoned = [[] for _ in range(T)]
         self._now = float(sm[3])
         self._flags = flags | _lib.FLAG_DONE
         self._replay_summary = sm

@@ -183,6 +183,11 @@ int dcm_get_agents(dcm_env *env, double *sum_wait, double *travel_dist, double *
  * (what generate_traj :390,:400 and the plotting code test membership against). */
 int dcm_get_members(dcm_env *env, int16_t *ids_out, void *stream);
 
+/* task['abandoned_agent'] (env/task_env.py:89) of every task as counts: counts_out uint16[B,A,T], [b,a,t] = number of times
+ * task t has moved agent a to its abandoned_agent list in the current episode (calculate_waiting_time :358-364 only uses
+ * membership and multiplicity; the order of the appends is not kept). */
+int dcm_get_abandoned(dcm_env *env, uint16_t *counts_out, void *stream);
+
 /* copy.deepcopy(env) (worker.py:33): snapshot / restore of the mutable SoA state.
  * dcm_state_bytes gives the buffer size (device memory) needed for all B envs. */
 int dcm_state_bytes(dcm_env *env, size_t *bytes_out);

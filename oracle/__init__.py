@@ -73,6 +73,9 @@ def lib():
         L.orc_final_agents.argtypes = [vp] * 5
         L.orc_get_route.restype = C.c_int
         L.orc_get_route.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+        for f in ("orc_get_members", "orc_get_abandoned"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [vp, C.c_int, vp, C.c_int]
         L.orc_pre_set_route.argtypes = [vp, C.c_int, vp, C.c_int]
         L.orc_execute_by_route.restype = C.c_int
         L.orc_execute_by_route.argtypes = [vp, C.c_int]
@@ -223,6 +226,18 @@ class OracleEnv:
         t, a = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
         n = lib().orc_get_route(self._h, int(agent), _p(t), _p(a), cap)
         return t[:n].copy(), a[:n].copy()
+
+    def members(self, task, cap=256):
+        """task['members'] in list order (env/task_env.py:78)."""
+        out = np.zeros(cap, np.int32)
+        n = lib().orc_get_members(self._h, int(task), _p(out), cap)
+        return out[:n].copy()
+
+    def abandoned(self, task, cap=4096):
+        """task['abandoned_agent'] in append order (env/task_env.py:89)."""
+        out = np.zeros(cap, np.int32)
+        n = lib().orc_get_abandoned(self._h, int(task), _p(out), cap)
+        return out[:n].copy()
 
     # route replay --------------------------------------------------------------------------
     def pre_set_route(self, actions, agent):

@@ -485,6 +485,18 @@ int orc_get_route(orc_env *e, int agent, int32_t *tasks_out, double *arrival_out
     return n;
 }
 
+/* task['members'] / task['abandoned_agent'] lists (env/task_env.py:78,89) in list order */
+int orc_get_members(orc_env *e, int task, int32_t *out, int cap) {
+    int n = e->members[task].n;
+    for (int i = 0; i < n && i < cap; i++) out[i] = e->members[task].v[i];
+    return n;
+}
+int orc_get_abandoned(orc_env *e, int task, int32_t *out, int cap) {
+    int n = e->abandoned[task].n;
+    for (int i = 0; i < n && i < cap; i++) out[i] = e->abandoned[task].v[i];
+    return n;
+}
+
 /* ------------------------------------------------------------------ RL-mode episode (worker.py:45-87) */
 static int policy_pick(orc_env *e, int policy, const uint8_t *mask, int leader, uint64_t seed_e, uint64_t d) {
     int T1 = e->T + 1;

@@ -82,6 +82,8 @@ void orc_final_agents(orc_env *e, double *agent_wait, double *travel_dist, uint8
 
 /* agent['route'] / agent['arrival_time'] (env/task_env.py:95-96): copies up to cap entries, returns the route length */
 int orc_get_route(orc_env *e, int agent, int32_t *tasks_out, double *arrival_out, int cap);
+int orc_get_members(orc_env *e, int task, int32_t *out, int cap);   /* task['members'], list order (env/task_env.py:78) */
+int orc_get_abandoned(orc_env *e, int task, int32_t *out, int cap); /* task['abandoned_agent'], append order (:89) */
 
 /* route replay: env/task_env.py:595-599 (pre_set_route), :562-593 (execute_by_route) */
 void orc_pre_set_route(orc_env *e, int agent, const int32_t *actions, int n);

@@ -71,6 +71,44 @@ def test_worker_loop_on_facade(gpu_device, golden_dir, name):
     assert set(("feasible_assignment", "finished", "time_start", "time_finish", "status", "requirements")) <= set(env.task_dic[0])
 
 
+@pytest.mark.parametrize("name", ["trace_10A20T_random_s1", "trace_20A50T_random_s0", "trace_20A50T_nearest_s0"])
+def test_dict_views_carry_route_and_member_lists(gpu_device, oracle_lib, golden_dir, name):
+    """agent_dic[i]['route'] / ['arrival_time'] (env/task_env.py:95-96; read by worker.py:244-251) and
+    task_dic[t]['members'] / ['abandoned_agent'] (:78,:89) of the facade against the oracle's own lists after the same
+    episode (golden actions; leaders and followers from the shared protocol)."""
+    from dcmrta_amd.task_env import TaskEnv
+    tr = H.load_trace(os.path.join(golden_dir, name + ".npz"))
+    A, T = int(tr["A"]), int(tr["T"])
+    env = TaskEnv.from_arrays(A, tr["depot"], tr["task_xy"], tr["req"], tr["dur"], device=gpu_device, choice_seed=int(tr["seed_e"]))
+    stop = int(tr["n_steps"]) // 2
+    seen_mid = {}
+
+    def act(d, mask):
+        if d == stop:      # mid-episode: the views are live, not only terminal
+            seen_mid["routes"] = [list(env.agent_dic[a]["route"]) for a in range(A)]
+            seen_mid["members"] = [list(env.task_dic[t]["members"]) for t in range(T)]
+        return int(tr["action"][d])
+    worker_loop(env, int(tr["seed_e"]), act)
+    o = oracle_lib.OracleEnv(A, T).load(tr["depot"], tr["task_xy"], tr["req"], tr["dur"])
+    ref = o.rollout(int(tr["seed_e"]), 0, oracle_lib.POLICY_INJECTED, inj_action=tr["action"].astype(np.int32))
+    assert ref["n_steps"] == int(tr["n_steps"])
+    ad, td = env.agent_dic, env.task_dic
+    n_ab = 0
+    for a in range(A):
+        route, arrival = o.route(a)
+        assert ad[a]["route"] == route.tolist() and ad[a]["arrival_time"] == arrival.tolist(), a
+        assert len(ad[a]["route"]) == ref["route_len"][a]
+        assert seen_mid["routes"][a] == route.tolist()[:len(seen_mid["routes"][a])]      # a prefix of the final route
+    for t in range(T):
+        assert td[t]["members"] == o.members(t).tolist(), t                               # list ORDER matters (quirk Q1)
+        assert sorted(td[t]["abandoned_agent"]) == sorted(o.abandoned(t).tolist()), t
+        assert len(td[t]["abandoned_agent"]) == ref["n_abandoned"][t]
+        n_ab += len(td[t]["abandoned_agent"])
+    if "random" in name:
+        assert n_ab > 0                                                                   # the random policy does abandon
+    assert any(seen_mid["members"])
+
+
 def test_step_returns_group_and_reward(gpu_device):
     from dcmrta_amd.task_env import TaskEnv
     env = TaskEnv((6, 6), (9, 9), 1, 5, seed=3, device=gpu_device, choice_seed=5)

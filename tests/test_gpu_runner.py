@@ -18,6 +18,7 @@ def test_job_contract_and_replay(gpu_device, oracle_lib):
     B, A, T = 6, 10, 20
     small = lambda: AttentionNet(6, 5, 32)
     r = BatchedRunner(metaAgentID=3, n_envs=B, device=gpu_device, net_factory=small, base_seed=11)
+    r.keep_greedy_record = True
     w = {k: v.clone() for k, v in r.get_weights().items()}
     jobResults, metrics, info = r.job(w, w, episodeNumber=2, agents_num=A, tasks_num=T, as_lists=True)
     assert info == {"id": 3, "episode_number": 2} and set(metrics) == set(METRIC_KEYS)
@@ -52,6 +53,35 @@ def test_job_contract_and_replay(gpu_device, oracle_lib):
         assert ref["reward"] == summary[b, 0]
         a = adv[lo:hi, 0].cpu().numpy()
         assert np.allclose(a, np.float32(summary[b, 0] - greedy[b, 0]))          # worker.py:92-101
+    # the greedy self-critic twin (worker.py:89,200-235: argmax of the same net on the same instance) is an episode of the
+    # reference env too: replay its recorded decisions through the oracle
+    _replay_recorded(oracle_lib, r.last["greedy_rec"], greedy, inst, seeds, A, T)
+    # ... and the argmax really was the greedy choice of the net on the recorded observations
+    g = r.last["greedy_rec"]
+    act = g["active"]
+    lp = r.localNetwork(g["tasks"][act], g["agents"][act], g["mask"][act])
+    assert (lp.gather(1, g["action"][act].unsqueeze(1))[:, 0] >= lp.max(1).values - 1e-4).all()
+
+
+def _replay_recorded(oracle_lib, rec, summary, inst, seeds, A, T, n_agents=None, n_tasks=None):
+    """Every episode of a recorded batched rollout ([S, B, ...] experience + `active`) through the oracle with the recorded
+    actions injected: leaders, observations, masks, reward and metrics must be the reference env's."""
+    act = rec["active"].cpu().numpy()
+    ag, tk, mk, ac, ld = (rec[k].cpu().numpy() for k in ("agents", "tasks", "mask", "action", "leader"))
+    summary = np.asarray(summary)
+    for b in range(act.shape[1]):
+        a = int(n_agents[b]) if n_agents is not None else A
+        t = int(n_tasks[b]) if n_tasks is not None else T
+        sel = act[:, b]
+        o = oracle_lib.OracleEnv(a, t).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_INJECTED, cap_steps=8192, inj_action=ac[sel, b].astype(np.int32))
+        assert ref["n_steps"] == int(sel.sum()), b
+        assert np.array_equal(ref["leader"], ld[sel, b]), b
+        assert np.array_equal(ref["agents_obs"], ag[sel, b, :a]) and np.array_equal(ref["tasks_obs"], tk[sel, b, :t + 1]), b
+        assert np.array_equal(ref["mask"], mk[sel, b, :t + 1].astype(np.uint8)), b
+        assert ref["reward"] == summary[b, 0], b
+        for i in range(6):
+            assert ref["metrics"][i] == summary[b, 2 + i], (b, i)
 
 
 def test_testing_greedy_is_deterministic(gpu_device):
@@ -135,12 +165,41 @@ def test_run_test_and_run_test_is(gpu_device, oracle_lib, golden_dir):
     inst, A = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
     sub = {k: v[:6] for k, v in inst.items()}
     r = BatchedRunner(n_envs=6, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32))
+    r.keep_greedy_record = True
+    from dcmrta_amd.choice import env_seeds
+    seeds = env_seeds(r.base_seed, 0, 6)
     for is_mode in (False, True):
         m = r.run_test(sub, n_agents=A, individual_selection=is_mode)
         assert set(m) == set(METRIC_KEYS) | {"reward"} and all(v.shape == (6,) for v in m.values())
         assert np.array_equal(m["reward"], -m["makespan"]) and (m["success_rate"] <= 1).all()
-        again = r.run_test(sub, n_agents=A, individual_selection=is_mode)
-        assert all(np.array_equal(m[k], again[k], equal_nan=True) for k in m)
+        rec, sm = r.last["rec"], r.last["summary"].cpu().numpy()
+        for k, name in enumerate(METRIC_KEYS):
+            assert np.array_equal(m[name], sm[:, 2 + k])
+        if not is_mode:
+            # leader-follower mode (worker.py:114-157): the recorded greedy episodes are episodes of the reference env
+            _replay_recorded(oracle_lib, rec, sm, sub, seeds, A, 50)
+        else:
+            # individual selection (worker.py:159-198): the reference loop restated on the oracle with the recorded actions
+            act, ac, ld = (rec[k].cpu().numpy() for k in ("active", "action", "leader"))
+            for b in range(6):
+                o = oracle_lib.OracleEnv(A, 50).load(sub["depot"][b], sub["task_xy"][b], sub["req"][b], sub["dur"][b])
+                acts, leads = ac[act[:, b], b], ld[act[:, b], b]
+                n, finished = 0, False
+                while not finished and o.now < 100:                              # worker.py:163
+                    ids, t = o.next_decision()
+                    o.now = t
+                    o.task_update(); o.agent_update()
+                    for a in ids:                                                # :170 ascending ids, each alone
+                        assert leads[n] == a, (b, n)
+                        o.agent_step(int(a), int(acts[n]))
+                        o.task_update(); o.agent_update()
+                        n += 1
+                    finished = o.check_finished()
+                oracle_lib.lib().orc_finish_episode(o._h)
+                f = o.final()
+                assert n == len(acts) and f["reward"] == sm[b, 0], b
+                for i in range(6):
+                    assert f["metrics"][i] == sm[b, 2 + i], (b, i)
     # individual selection, stepwise against the oracle: same decisions -> same final state
     env = BatchedTaskEnv(1, A, 50, device=gpu_device, individual_selection=True)
     env.load_instances(**{k: v[:1] for k, v in sub.items()})
@@ -163,3 +222,115 @@ def test_run_test_and_run_test_is(gpu_device, oracle_lib, golden_dir):
     oracle_lib.lib().orc_finish_episode(o._h)
     assert not bool(obs.active[0]) and n > 20
     assert env.summary()[0, 0].item() == o.final()["reward"]
+
+
+def test_masked_action_policy_is_reported(gpu_device):
+    """A policy that ignores the mask makes the device freeze envs (DCM_FLAG_BAD_ACTION) whose summary rows stay NaN: the
+    runner must raise instead of averaging NaN rewards into the batch."""
+    from dcmrta_amd.runner import BatchedRunner, EnvError
+
+    class IgnoresMask(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, tasks, agents, mask):           # always prefers task 1, masked or not
+            lp = torch.full(mask.shape, -5.0, device=mask.device) + self.w
+            lp[:, 1] = 0.0
+            return torch.log_softmax(lp, dim=1)
+    r = BatchedRunner(n_envs=4, device=gpu_device, net_factory=IgnoresMask)
+    w = r.get_weights()
+    with pytest.raises(EnvError, match="frozen by the device"):
+        r.job(w, w, 0, 6, 9)
+
+
+def test_learner_step_on_runner_output(gpu_device):
+    """driver.py:99-199 against dcmrta_amd.ray_compat: actors, job.remote, wait / get, the experience buffer, a 1024-decision
+    batch, forward, gather, REINFORCE loss, backward, clipped optimizer step -- restated call for call."""
+    import copy
+    import random
+    from dcmrta_amd import ray_compat as ray
+    from dcmrta_amd.ray_compat import RLRunner
+    from dcmrta_amd.policy import AttentionNet
+    torch.manual_seed(3)
+    NUM_META_AGENT, BATCH_SIZE, D = 2, 1024, 32
+    factory = lambda: AttentionNet(6, 5, D)
+    ray.init(n_envs=24, net_factory=factory, base_seed=5)
+    device = torch.device(gpu_device)
+    global_network, baseline_network = factory().to(device), factory().to(device)
+    global_optimizer = torch.optim.Adam(global_network.parameters(), lr=1e-4)
+    meta_agents = [RLRunner.remote(i) for i in range(NUM_META_AGENT)]                     # driver.py:99
+    weights, baseline_weights = global_network.state_dict(), baseline_network.state_dict()
+    curr_episode, jobList = 0, []
+    agents_num, tasks_num = 12, 23
+    for meta_agent in meta_agents:                                                          # :116-118
+        jobList.append(meta_agent.job.remote(weights, baseline_weights, curr_episode, agents_num, tasks_num))
+        curr_episode += 1
+    metric_name = ['success_rate', 'makespan', 'time_cost', 'waiting_time', 'travel_dist', 'efficiency']
+    experience_buffer = [[] for _ in range(9)]
+    updates = 0
+    before = copy.deepcopy(global_network.state_dict())
+    for _ in range(2):
+        done_id, jobList = ray.wait(jobList, num_returns=NUM_META_AGENT)                  # :129
+        done_jobs = ray.get(done_id)                                                        # :130
+        random.shuffle(done_jobs)
+        perf_metrics = {n: [] for n in metric_name}
+        for job in done_jobs:                                                               # :135-140
+            jobResults, metrics, info = job
+            for i in range(9):
+                experience_buffer[i] += jobResults[i]
+            for n in metric_name:
+                perf_metrics[n].append(metrics[n])
+        assert set(info) >= {"id", "episode_number"}
+        while len(experience_buffer[0]) >= BATCH_SIZE:                                      # :143-188
+            rollouts = copy.copy(experience_buffer)
+            for i in range(len(rollouts)):
+                rollouts[i] = rollouts[i][:BATCH_SIZE]
+            for i in range(len(experience_buffer)):
+                experience_buffer[i] = experience_buffer[i][BATCH_SIZE:]
+            agent_inputs = torch.stack(rollouts[0], dim=0)
+            task_inputs = torch.stack(rollouts[1], dim=0)
+            action_batch = torch.stack(rollouts[2], dim=0)
+            mask_batch = torch.stack(rollouts[3], dim=0)
+            advantage_batch = torch.stack(rollouts[6], dim=0)
+            reward_batch = torch.stack(rollouts[4], dim=0)
+            index = torch.stack(rollouts[5])
+            assert agent_inputs.shape == (BATCH_SIZE, agents_num, 6) and task_inputs.shape == (BATCH_SIZE, tasks_num + 1, 5)
+            assert action_batch.shape == (BATCH_SIZE, 1) and index.shape == (BATCH_SIZE, 1, 1) and reward_batch.shape == (BATCH_SIZE, 1)
+            logp_list = global_network(task_inputs, agent_inputs, mask_batch)               # :175
+            logp = torch.gather(logp_list, 1, action_batch)                                 # :176
+            entropy = (logp_list * logp_list.exp()).nansum(dim=-1).mean()
+            policy_loss = (- logp * advantage_batch.detach()).mean()
+            global_optimizer.zero_grad()
+            policy_loss.backward()
+            grad_norm = torch.nn.utils.clip_grad_norm_(global_network.parameters(), max_norm=10, norm_type=2)
+            global_optimizer.step()
+            assert torch.isfinite(policy_loss) and torch.isfinite(entropy) and torch.isfinite(grad_norm) and grad_norm > 0
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in global_network.parameters())
+            assert (logp > -9000).all()                                                     # sampled actions were never masked
+            updates += 1
+        weights = global_network.state_dict()
+        for meta_agent in meta_agents:                                                      # :197-199
+            jobList.append(meta_agent.job.remote(weights, baseline_weights, curr_episode, agents_num, tasks_num))
+            curr_episode += 1
+    assert updates >= 2 and np.isfinite(np.nanmean(perf_metrics["makespan"]))
+    after = global_network.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)                        # the learner really moved
+    # evaluation calls of driver.py:241-252: fresh actors, set_baseline_weights, testing(seed=...), kill
+    ray.wait(jobList, num_returns=NUM_META_AGENT)
+    for a in meta_agents:
+        ray.kill(a)
+    test_agent_list = [RLRunner.remote(metaAgentID=i) for i in range(NUM_META_AGENT)]
+    for test_agent in test_agent_list:
+        ray.get(test_agent.set_baseline_weights.remote(baseline_weights))
+    sample_job_list = [test_agent.testing.remote(seed=1000 + j) for j, test_agent in enumerate(test_agent_list)]
+    sample_done_id, _ = ray.wait(sample_job_list, num_returns=NUM_META_AGENT)
+    reward = ray.get(sample_done_id)
+    assert len(reward) == NUM_META_AGENT and all(isinstance(x, float) and x < 0 for x in reward)
+    for a in test_agent_list:
+        ray.kill(a)
+    # a failing call surfaces from get, like a Ray task error
+    bad = RLRunner.remote(0)
+    with pytest.raises(Exception):
+        ray.get(bad.job.remote({}, {}, 0, 5, 8))
+    ray.kill(bad)
