@@ -7,7 +7,10 @@ Prints one JSON line per config (1 GPU; config 4's sharded variant is bench.py -
   1   1 env, 20A/50T test-set instance 0: oracle (CPU, 1 thread) vs HIP lockstep, per-step latency
   2l  config 2 through the LOCKSTEP API (dcm_step per decision, uniform-random valid action chosen by a torch op)
   2g  the same loop as eager launches vs ONE HIP graph per decision
-  3   4096 envs 20A/50T, attention policy (stock PyTorch-ROCm) + HIP env step: env-only and end-to-end
+  3   4096 envs 20A/50T, attention policy (stock PyTorch-ROCm) + HIP env step: eager fp32 / HIP graph fp32 / HIP graph with a
+      bf16 and an fp16 shadow of the net, policy : env time split, end-to-end steps/s
+  6   runtime-shape path: the persistent kernel and k_step at 4096 x 15A/35T, 4096 x 20A/49T and a ragged (10-20) x (20-50)
+      batch next to the exact 20A/50T instantiation
   4   8192 envs/GPU 50A/200T random-policy rollout (the per-GPU shard of 65536 envs over 8 GPUs)
   5   100A/500T route replay, synthetic routes, with/without dynamic visibility
 """
@@ -117,22 +120,101 @@ def config2_graph(A=20, T=50):
 
 
 def config3(B=4096, A=20, T=50):
+    """BASELINE configs[2]: one sampled episode per env, policy in the loop.  Variants: the lockstep loop with a host sync per
+    decision (round 1), and the captured HIP graph per decision (no host sync, check_every = 8) in fp32 / bf16 / fp16."""
+    from dcmrta_amd.graph_rollout import GraphedRollout
     from dcmrta_amd.policy import AttentionNet
     torch.manual_seed(0)
     net = AttentionNet().to(DEV).eval()
+    net.assume_no_padding = True
     inst = generate_batch(B, A, T, 0)
     env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
     seeds = env_seeds(0, 0, B)
+    rows = {}
 
-    @torch.no_grad()
-    def policy(ob):
-        return torch.distributions.Categorical(logits=net(ob.tasks, ob.agents, ob.mask)).sample().to(torch.int32)
+    def sampler(m):
+        @torch.no_grad()
+        def policy(ob):
+            lp = m(ob.tasks, ob.agents, ob.mask)                       # Categorical(logp.exp()).sample() as an exponential race
+            return torch.argmax(lp - torch.empty_like(lp).exponential_(1.0).log(), dim=1).to(torch.int32)
+        return policy
+    # eager, fp32, one host sync per decision
+    pol = sampler(net)
+    lockstep_episode(env, seeds, pol)
     sync(); t0 = time.perf_counter()
-    n, t_env = lockstep_episode(env, seeds, policy)
+    n, t_env = lockstep_episode(env, seeds, pol)
     wall = time.perf_counter() - t0
-    return dict(config=3, workload=f"{B} envs {A}A/{T}T, attention policy fp32 (2.1M params) + HIP env step",
-                steps_per_s_end_to_end=n / wall, steps_per_s_env_only=n / t_env, policy_share=1 - t_env / wall,
-                mean_reward=float(env.summary()[:, 0].mean()))
+    rows["eager_fp32"] = dict(steps_per_s_end_to_end=n / wall, steps_per_s_env_only=n / t_env, policy_share=1 - t_env / wall,
+                              mean_reward=float(env.summary()[:, 0].mean()))
+    # env-only cost of one batched dcm_step at this batch (for the split of the graphed variants)
+    obs = env.reset(seeds)
+    act = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ev = []
+    for _ in range(60):
+        act.copy_(torch.argmax((~obs.mask).to(torch.int32), dim=1))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); obs = env.step(act); e1.record()
+        ev.append((e0, e1))
+    sync()
+    env_ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+    for name, m in (("graph_fp32", net), ("graph_bf16", net.rollout_copy(torch.bfloat16)), ("graph_fp16", net.rollout_copy(torch.float16))):
+        g = GraphedRollout(env, sampler(m), check_every=8)
+        g.run(seeds)
+        sync(); t0 = time.perf_counter()
+        summary, batched = g.run(seeds)
+        sync(); wall = time.perf_counter() - t0
+        dec = int(env.status()["decisions"].sum())
+        rows[name] = dict(steps_per_s_end_to_end=dec / wall, batched_steps=batched, ms_per_batched_step=wall / batched * 1e3,
+                          env_ms_per_batched_step=env_ms, policy_share=1 - env_ms / (wall / batched * 1e3),
+                          active_fraction=dec / (batched * B), mean_reward=float(summary[:, 0].mean()))
+    return dict(config=3, workload=f"{B} envs {A}A/{T}T, attention policy (2.1M params, stock PyTorch) sampled + HIP env step, "
+                                   f"one episode per env", **rows)
+
+
+def config6(B=4096):
+    """Runtime-shape path (training draws (agents_num, tasks_num) afresh every round, driver.py:114-115)."""
+    from dcmrta_amd.instances import generate_batch_ranges
+    rows = {}
+
+    def rollout_rate(env, episodes=3, reps=5):
+        env.rollout_random(episodes)
+        sync(); t0 = time.perf_counter(); n = 0
+        for _ in range(reps):
+            n += int(env.rollout_random(episodes).sum())
+        sync()
+        return n / (time.perf_counter() - t0)
+
+    def step_us(env, seeds, n=80):
+        obs = env.reset(seeds)
+        act = torch.zeros(env.B, dtype=torch.int32, device=DEV)
+        ev = []
+        for _ in range(n):
+            act.copy_(torch.multinomial((~obs.mask).float(), 1).squeeze(1))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); obs = env.step(act); e1.record()
+            ev.append((e0, e1))
+        sync()
+        return sorted(a.elapsed_time(b) for a, b in ev)[n // 2] * 1e3
+    warm = BatchedTaskEnv(B, 20, 50, device=DEV).load_instances(**generate_batch(B, 20, 50, 0))   # clocks up before the first row
+    warm.reset(env_seeds(0, 0, B), observe=False)
+    for _ in range(30):
+        warm.rollout_random(3)
+    sync()
+    warm.close()
+    for name, (A, T) in (("20A50T exact <20,50>", (20, 50)), ("20A49T <20,50,runtime sizes>", (20, 49)),
+                         ("15A35T <20,50,runtime sizes>", (15, 35)), ("21A51T generic <0,0>", (21, 51))):
+        env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**generate_batch(B, A, T, 0))
+        seeds = env_seeds(0, 0, B)
+        env.reset(seeds, observe=False)
+        rows[name] = dict(rollout_steps_per_s=rollout_rate(env), k_step_us_per_batched_step=step_us(env, seeds))
+        env.close()
+    rag = generate_batch_ranges(range(B), (10, 20), (20, 50))
+    env = BatchedTaskEnv(B, 20, 50, device=DEV).load_instances(**rag)
+    seeds = env_seeds(0, 0, B)
+    env.reset(seeds, observe=False)
+    rows["ragged (10-20)x(20-50) <20,50,runtime sizes>"] = dict(rollout_steps_per_s=rollout_rate(env),
+                                                                k_step_us_per_batched_step=step_us(env, seeds))
+    return dict(config=6, workload=f"{B} envs, runtime-shape instantiations vs the exact one (one stream, 3 episodes per launch)", **rows)
 
 
 def config4(B=8192, A=50, T=200, reps=3):
@@ -144,9 +226,9 @@ def config4(B=8192, A=50, T=200, reps=3):
     for _ in range(reps):
         n += int(env.rollout_random(1).sum())
     sync(); dt = time.perf_counter() - t0
-    W = algorithmic_bytes_per_step(A, T)
-    return dict(config=4, workload=f"{B} envs/GPU {A}A/{T}T random-policy rollout (shard of 65536 over 8 GPUs)",
-                steps_per_s=n / dt, hbm_frac=n / dt * W / HBM_PEAK_BYTES_PER_S, decisions_per_episode=n / reps / B)
+    return dict(config=4, workload=f"{B} envs/GPU {A}A/{T}T random-policy rollout (shard of 65536 over 8 GPUs; the whole config: "
+                                   f"bench.py --config 4 [--gpus N])",
+                steps_per_s=n / dt, decisions_per_episode=n / reps / B)
 
 
 def config5(B=1024, A=100, T=500):
@@ -172,6 +254,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
     a = ap.parse_args()
-    table = {"1": config1, "2l": config2_lockstep, "2g": config2_graph, "3": config3, "4": config4, "5": config5}
+    table = {"1": config1, "2l": config2_lockstep, "2g": config2_graph, "3": config3, "4": config4, "5": config5, "6": config6}
     for k in (table if a.config == "all" else [a.config]):
         print(json.dumps(table[k]()), flush=True)

@@ -340,7 +340,7 @@ struct Sim {
 
     // ------------------------------------------------------------------------------ terminal
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
-    // Returns true when some agent's abandonment log overflowed (see DCM_FLAG_WAIT_ORDER).
+    // Returns true when a per-(agent, task) abandonment counter saturated (DCM_FLAG_WAIT_ORDER; the only inexact case).
     __device__ bool compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A(), PT_ = PT();
         const int TW = (int)L().twords();

@@ -109,8 +109,12 @@ class BatchedRunner:
     # ------------------------------------------------------------------ one batched episode (worker.py:45-87)
     @staticmethod
     def _select(mode):
-        if mode == "sample":      # worker.py:70: Categorical(logp.exp()).sample()
-            return lambda logp, mask: torch.multinomial(logp.exp(), 1).squeeze(1)
+        if mode == "sample":
+            # worker.py:70: Categorical(logp.exp()).sample().  Drawn as argmax(p / q), q ~ Exp(1) (the "exponential race",
+            # which is also what torch.multinomial does for one sample) written out on the log-probabilities: no exp(), graph-
+            # capturable (torch.multinomial on these probabilities faults under HIP-graph replay at B = 4096 on ROCm 7.2), and
+            # a masked action (logp ~ -1e4, attention.py:76) can never win: -log q <= 88 in fp32
+            return lambda logp, mask: torch.argmax(logp - torch.empty_like(logp).exponential_(1.0).log(), dim=1)
         if mode == "greedy":      # worker.py:228
             return lambda logp, mask: torch.argmax(logp, dim=1)
         if mode == "test":        # worker.py:140 / :185
