@@ -74,14 +74,20 @@ struct Lay {
     __host__ __device__ constexpr uint32_t ty() const { return mut_bytes() + 8 * T; }
     __host__ __device__ constexpr uint32_t tdur() const { return mut_bytes() + 16 * T; }
     __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
-    __host__ __device__ constexpr uint32_t tw() const { return rec_bytes(); }        // scratch f64[T] (LDS only)
-    __host__ __device__ constexpr uint32_t aw() const { return rec_bytes() + 8 * T; }  // scratch f64[A]
-    __host__ __device__ constexpr uint32_t aux() const { return align16(rec_bytes() + 8 * T + 8 * A); }  // 32 B: log pointer, incremental-update state, count-table pointer
-    __host__ __device__ constexpr uint32_t absort() const { return aux() + 32; }     // scratch u16[A][AB_CAP]
-    __host__ __device__ constexpr uint32_t tmx() const { return align16(absort() + 2 * AB_CAP * A); }   // scratch f64[T]
+    // LDS image of a record = the record + 32 B: abandonment-log pointer, incremental-update state, count-table pointer
+    __host__ __device__ constexpr uint32_t aux() const { return rec_bytes(); }
+    __host__ __device__ constexpr uint32_t lds_rec() const { return rec_bytes() + 32; }
+    // Scratch of the terminal metrics (calculate_waiting_time), offsets relative to its own base: behind the record in LDS
+    // for the persistent kernel of the small shapes, a per-env HBM buffer otherwise (an episode ends once in ~120 decisions;
+    // keeping 1.8 KB of LDS per env for it costs k_step 6 of its 27 resident workgroups per CU)
+    __host__ __device__ constexpr uint32_t s_tw() const { return 0; }                                    // f64[T]
+    __host__ __device__ constexpr uint32_t s_aw() const { return 8 * T; }                                // f64[A]
+    __host__ __device__ constexpr uint32_t s_absort() const { return align16(8 * T + 8 * A); }           // u16[A][AB_CAP]
+    __host__ __device__ constexpr uint32_t s_tmx() const { return align16(s_absort() + 2 * AB_CAP * A); }  // f64[T]
     __host__ __device__ constexpr uint32_t twords() const { return (uint32_t)(T + 63) / 64; }
-    __host__ __device__ constexpr uint32_t amask() const { return tmx() + 8 * T; }                       // scratch u64[A][twords]
-    __host__ __device__ constexpr uint32_t lds_bytes() const { return align16(amask() + 8 * A * twords()); }
+    __host__ __device__ constexpr uint32_t s_amask() const { return s_tmx() + 8 * T; }                   // u64[A][twords]
+    __host__ __device__ constexpr uint32_t scratch_bytes() const { return align16(s_amask() + 8 * A * twords()); }
+    __host__ __device__ constexpr uint32_t lds_bytes() const { return lds_rec() + scratch_bytes(); }     // record + scratch in LDS
 };
 static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
 
@@ -301,6 +307,7 @@ struct dcm_env {
                                      // training range, so those shapes share one constant-offset kernel instantiation)
     dcm::KP kp;
     unsigned char* state = nullptr;  // [B][rec_bytes]
+    unsigned char* gscratch = nullptr;  // [B][scratch_bytes] terminal-metrics scratch of the kernels that keep it out of LDS
     double* summary = nullptr;       // [B][8]
     uint16_t* ablog = nullptr;       // [B][A][AB_CAP] abandonment log (side table of the state)
     bool loaded = false, reset_done = false;

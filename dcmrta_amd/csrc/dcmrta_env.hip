@@ -68,6 +68,10 @@ struct Sim {
     int rA, rT;           // this env's own sizes (ignored by the exact instantiation)
     int pA, pT;           // record layout dims (read by the <0,0> instantiation only)
     unsigned char* base;  // record base (LDS in the env kernels)
+    unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
+    // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
+    // BASELINE batch be resident); every other kernel trades it for more resident workgroups
+    static constexpr bool SCR_IN_LDS = (CA != 0 && CA <= WAVE && CT <= WAVE);
 
     __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }
     __device__ __forceinline__ int T() const { return EXACT ? CT : rT; }
@@ -113,11 +117,11 @@ struct Sim {
     __device__ __forceinline__ double* tx() const { return (double*)(base + L().tx()); }
     __device__ __forceinline__ double* ty() const { return (double*)(base + L().ty()); }
     __device__ __forceinline__ double* tdur() const { return (double*)(base + L().tdur()); }
-    __device__ __forceinline__ double* tw() const { return (double*)(base + L().tw()); }
-    __device__ __forceinline__ double* aw() const { return (double*)(base + L().aw()); }
-    __device__ __forceinline__ uint16_t* absort() const { return (uint16_t*)(base + L().absort()); }
-    __device__ __forceinline__ double* tmx() const { return (double*)(base + L().tmx()); }
-    __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(base + L().amask()); }
+    __device__ __forceinline__ double* tw() const { return (double*)(scr + L().s_tw()); }
+    __device__ __forceinline__ double* aw() const { return (double*)(scr + L().s_aw()); }
+    __device__ __forceinline__ uint16_t* absort() const { return (uint16_t*)(scr + L().s_absort()); }
+    __device__ __forceinline__ double* tmx() const { return (double*)(scr + L().s_tmx()); }
+    __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(scr + L().s_amask()); }
     // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
     __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + L().aux()); }
     __device__ __forceinline__ uint8_t* abcnt() const { return *(uint8_t* const*)(base + L().aux() + 16); }
@@ -928,12 +932,14 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, i
 
 template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP P, unsigned char* state, const uint64_t* seeds,
-                                               double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
+                                               double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes,
+                                               unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
+    S.scr = gscr + (size_t)e * L.scratch_bytes();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     WSYNC();
@@ -958,7 +964,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};   // (observe never reaches the terminal metrics: no scratch)
     const Lay L = S.L();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
@@ -989,13 +995,14 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
-                                              uint16_t* ablog, uint32_t mode, const int32_t* sizes) {
+                                              uint16_t* ablog, uint32_t mode, const int32_t* sizes, unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
     using AMask = typename Sim<CA, CT, RS>::AMask;
     const Lay L = S.L();
+    S.scr = gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
@@ -1047,13 +1054,15 @@ template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
-                                                        const int32_t* sizes, int64_t budget_all, const int64_t* budget_in) {
+                                                        const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
+                                                        unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem};
+    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
     using AMask = typename Sim<CA, CT, RS>::AMask;
     const Lay L = S.L();
+    S.scr = Sim<CA, CT, RS>::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
@@ -1125,12 +1134,14 @@ __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsig
 __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
-                                                   int32_t* n_abandoned, uint16_t* ablog, const int32_t* sizes) {
+                                                   int32_t* n_abandoned, uint16_t* ablog, const int32_t* sizes,
+                                                   unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    Sim<0, 0, false> S{eA, eT, PA, PT, smem};
+    Sim<0, 0, false> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
+    S.scr = gscr + (size_t)e * L.scratch_bytes();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
@@ -1155,12 +1166,13 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int P
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
                                                     int32_t* current, int32_t* pending, uint16_t* ablog,
-                                                    const int32_t* sizes) {
+                                                    const int32_t* sizes, unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    Sim<0, 0, false> S{eA, eT, PA, PT, smem};
+    Sim<0, 0, false> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
+    S.scr = gscr + (size_t)e * L.scratch_bytes();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
@@ -1280,28 +1292,32 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : Lay{h->A, h->T};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
-    if (h->L.lds_bytes() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
+    if (h->L.lds_rec() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
     const size_t bytes = (size_t)params->n_envs * h->L.rec_bytes();
     hipError_t e1 = hipMalloc((void**)&h->state, bytes);
     hipError_t e2 = hipMalloc((void**)&h->summary, (size_t)params->n_envs * 8 * sizeof(double));
     if (e1 == hipSuccess && e2 == hipSuccess)
         e2 = hipMalloc((void**)&h->ablog, side_bytes(params->n_envs, params->n_agents, params->n_tasks));
+    if (e1 == hipSuccess && e2 == hipSuccess)
+        e2 = hipMalloc((void**)&h->gscratch, (size_t)params->n_envs * h->L.scratch_bytes());
     if (e1 != hipSuccess || e2 != hipSuccess) {
         if (h->state) (void)hipFree(h->state);
         if (h->summary) (void)hipFree(h->summary);
         if (h->ablog) (void)hipFree(h->ablog);
+        if (h->gscratch) (void)hipFree(h->gscratch);
         delete h;
         return fail(DCM_ERR_HIP, "dcm_create: hipMalloc failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
     hipError_t e3 = hipMemset(h->state, 0, bytes);
     if (e3 == hipSuccess) e3 = hipMemset(h->ablog, 0, side_bytes(params->n_envs, params->n_agents, params->n_tasks));
-    if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); (void)hipFree(h->ablog); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
+    if (e3 != hipSuccess) { (void)hipFree(h->state); (void)hipFree(h->summary); (void)hipFree(h->ablog); (void)hipFree(h->gscratch); delete h; return fail(DCM_ERR_HIP, "hipMemset: %s", hipGetErrorString(e3)); }
     // kernels that keep the record in LDS may need more than the default 64 KiB of dynamic LDS.  The limit is a
     // per-function, per-device attribute shared by every handle of the process, so it only ever grows: a later, smaller
     // env must not lower it under an earlier handle's launches.
     static int lds_limit[64] = {0};
     const int dev_slot = params->device & 63;
-    int lds = (int)h->L.lds_bytes();
+    int lds = (int)h->L.lds_rec();
+    if (h->L.A <= WAVE && h->L.T <= WAVE) lds = (int)h->L.lds_bytes();    // persistent kernel of the one-chunk shapes: scratch in LDS
     if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
     lds_limit[dev_slot] = lds;
 #define SET_ATTR(CA, CT, RS)                                                                                             \
@@ -1323,6 +1339,7 @@ int dcm_destroy(dcm_env* env) {
     if (env->state) (void)hipFree(env->state);
     if (env->summary) (void)hipFree(env->summary);
     if (env->ablog) (void)hipFree(env->ablog);
+    if (env->gscratch) (void)hipFree(env->gscratch);
     if (env->routes) (void)hipFree(env->routes);
     if (env->route_len) (void)hipFree(env->route_len);
     if (env->sizes) (void)hipFree(env->sizes);
@@ -1373,8 +1390,8 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT, RS)                                                                                              \
-    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp, \
-                       env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes)
+    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp, \
+                       env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1398,7 +1415,7 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
 #define CALL(CA, CT, RS)                                                                                                \
-    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env),          \
+    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env),            \
                        env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
                        (const int32_t*)env->sizes, env->p.flags)
     DISPATCH_ENV(env, CALL);
@@ -1416,9 +1433,9 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
 #define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp, \
+    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes)
+                       active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1431,9 +1448,10 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
 #define CALL(CA, CT, RS)                                                                                              \
-    hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), \
+    hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
+                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : env->L.lds_rec()), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
-                       (const int32_t*)env->sizes, max_decisions, max_decisions_in)
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1460,9 +1478,9 @@ int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, do
 int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* time_start, double* time_finish,
                   double* sum_wait, int32_t* status, int32_t* n_members, int32_t* n_abandoned, void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp,
+    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,
                        env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned,
-                       env->ablog, (const int32_t*)env->sizes);
+                       env->ablog, (const int32_t*)env->sizes, env->gscratch);
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1471,9 +1489,9 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
                    double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, int32_t* pending_group,
                    void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_bytes(), (hipStream_t)stream, DIMS(env), env->kp,
+    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,
                        env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
-                       pending_group, env->ablog, (const int32_t*)env->sizes);
+                       pending_group, env->ablog, (const int32_t*)env->sizes, env->gscratch);
     LAUNCH_OK();
     return DCM_OK;
 }
