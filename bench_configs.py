@@ -176,13 +176,14 @@ def config6(B=4096):
     from dcmrta_amd.instances import generate_batch_ranges
     rows = {}
 
-    def rollout_rate(env, episodes=3, reps=5):
-        env.rollout_random(episodes)
-        sync(); t0 = time.perf_counter(); n = 0
-        for _ in range(reps):
-            n += int(env.rollout_random(episodes).sum())
+    def rollout_rate(env, episodes=3, reps=8):
+        for _ in range(3):
+            env.rollout_random(episodes)
+        sync(); t0 = time.perf_counter()
+        counts = [env.rollout_random(episodes) for _ in range(reps)]
         sync()
-        return n / (time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        return int(torch.stack(counts).sum()) / dt
 
     def step_us(env, seeds, n=80):
         obs = env.reset(seeds)
@@ -202,7 +203,7 @@ def config6(B=4096):
     sync()
     warm.close()
     for name, (A, T) in (("20A50T exact <20,50>", (20, 50)), ("20A49T <20,50,runtime sizes>", (20, 49)),
-                         ("15A35T <20,50,runtime sizes>", (15, 35)), ("21A51T generic <0,0>", (21, 51))):
+                         ("15A35T <20,50,runtime sizes>", (15, 35)), ("21A51T <64,64,runtime sizes>", (21, 51)), ("70A130T generic <0,0>", (70, 130))):
         env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**generate_batch(B, A, T, 0))
         seeds = env_seeds(0, 0, B)
         env.reset(seeds, observe=False)

@@ -304,7 +304,8 @@ struct dcm_env {
     dcm_params p;
     int A = 0, T = 0;                // batch dims = p.n_agents / p.n_tasks: shapes of every array crossing the ABI
     dcm::Lay L;                      // record layout dims (>= the batch dims: Lay{20,50} for every shape inside the reference's
-                                     // training range, so those shapes share one constant-offset kernel instantiation)
+                                     // training range, Lay{64,64} for the other one-chunk shapes, so that those shapes share
+                                     // constant-offset kernel instantiations)
     dcm::KP kp;
     unsigned char* state = nullptr;  // [B][rec_bytes]
     unsigned char* gscratch = nullptr;  // [B][scratch_bytes] terminal-metrics scratch of the kernels that keep it out of LDS

@@ -71,7 +71,7 @@ struct Sim {
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
     // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
     // BASELINE batch be resident); every other kernel trades it for more resident workgroups
-    static constexpr bool SCR_IN_LDS = (CA != 0 && CA <= WAVE && CT <= WAVE);
+    static constexpr bool SCR_IN_LDS = (CA != 0 && Lay{CA, CT}.lds_bytes() <= 10240);   // 16 workgroups per CU still fit
 
     __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }
     __device__ __forceinline__ int T() const { return EXACT ? CT : rT; }
@@ -1246,13 +1246,15 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
 
 // ---------------------------------------------------------------------------------- host side
 // Instantiations: the three BASELINE shapes exactly; <20,50,runtime sizes> for every other shape (uniform or ragged) inside
-// the reference's training range A <= 20, T <= 50 (parameters.py:15-16); <0,0> for the rest.
-#define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(50, 200, false); X(100, 500, false); X(0, 0, false)
+// the reference's training range A <= 20, T <= 50 (parameters.py:15-16); <64,64,runtime sizes> for the remaining one-chunk
+// shapes (A <= 64, T <= 64: one lane per agent / task); <0,0> for the rest.
+#define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(64, 64, true); X(50, 200, false); X(100, 500, false); X(0, 0, false)
 #define DISPATCH_ENV(env, CALL)                                                                        \
     do {                                                                                               \
         const dcm_env* e_ = (env);                                                                     \
         const bool exact_ = !e_->sizes && e_->A == e_->L.A && e_->T == e_->L.T;                        \
         if (e_->L.A == 20 && e_->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } } \
+        else if (e_->L.A == 64 && e_->L.T == 64) { CALL(64, 64, true); }                               \
         else if (exact_ && e_->A == 50 && e_->T == 200) { CALL(50, 200, false); }                      \
         else if (exact_ && e_->A == 100 && e_->T == 500) { CALL(100, 500, false); }                    \
         else { CALL(0, 0, false); }                                                                    \
@@ -1289,7 +1291,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     if (!h) return fail(DCM_ERR_INVALID, "dcm_create: out of host memory");
     h->p = *params;
     h->A = params->n_agents; h->T = params->n_tasks;
-    h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : Lay{h->A, h->T};
+    h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : (h->A <= 64 && h->T <= 64) ? Lay{64, 64} : Lay{h->A, h->T};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
     if (h->L.lds_rec() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
@@ -1317,7 +1319,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     static int lds_limit[64] = {0};
     const int dev_slot = params->device & 63;
     int lds = (int)h->L.lds_rec();
-    if (h->L.A <= WAVE && h->L.T <= WAVE) lds = (int)h->L.lds_bytes();    // persistent kernel of the one-chunk shapes: scratch in LDS
+    if (h->L.lds_bytes() <= 10240) lds = (int)h->L.lds_bytes();           // persistent kernel of the small layouts: scratch in LDS
     if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
     lds_limit[dev_slot] = lds;
 #define SET_ATTR(CA, CT, RS)                                                                                             \

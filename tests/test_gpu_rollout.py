@@ -50,7 +50,7 @@ def _check_last_decision(env, refs, taken, tag, ran=None):
         assert np.array_equal(mk2[b].astype(np.uint8), ref["mask"][k]), name
 
 
-@pytest.mark.parametrize("A,T,B,stops", [(20, 50, 48, 6), (50, 200, 32, 4), (15, 35, 32, 5), (12, 23, 16, 4), (70, 130, 6, 3)])
+@pytest.mark.parametrize("A,T,B,stops", [(20, 50, 48, 6), (50, 200, 32, 4), (15, 35, 32, 5), (12, 23, 16, 4), (33, 60, 12, 3), (70, 130, 6, 3)])
 def test_per_decision_outputs_at_random_indices(gpu_device, oracle_lib, A, T, B, stops):
     """Stop every env after random decision indices (per-env budgets) and compare what the persistent kernel stored for
     that decision with the oracle's recorded rec_agents / rec_tasks / rec_mask (oracle/dcmrta_oracle.c:569-576); carry on;
