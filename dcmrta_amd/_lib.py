@@ -49,6 +49,7 @@ SIGNATURES = {
     "dcm_get_tasks": (C.c_int, [_vp] * 10),
     "dcm_get_agents": (C.c_int, [_vp] * 12),
     "dcm_get_abandoned": (C.c_int, [_vp] * 3),
+    "dcm_env_episodes": (C.c_int, [_vp] * 3),
     "dcm_get_members": (C.c_int, [_vp] * 3),
     "dcm_state_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "dcm_clone_state": (C.c_int, [_vp] * 3),

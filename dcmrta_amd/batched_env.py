@@ -42,7 +42,7 @@ def _ptr(t):
 
 class BatchedTaskEnv:
     def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
-                 individual_selection=False):
+                 individual_selection=False, auto_reset=False):
         self._h = None
         self._lib = _lib.load()
         self.device = torch.device(device)
@@ -55,7 +55,10 @@ class BatchedTaskEnv:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
         # individual_selection: Worker.run_test_IS (worker.py:159-198) -- deciders are not grouped by location
-        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, 1 if individual_selection else 0, 0)
+        # auto_reset: step() restarts an env from its instance in the call that ends its episode (DCM_PARAM_AUTO_RESET): the
+        # batch stays full; summary() holds each env's last finished episode, episodes() counts them
+        flags = (1 if individual_selection else 0) | (2 if auto_reset else 0)
+        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, flags, 0)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self._lib.dcm_create(C.byref(p), C.byref(h)))
@@ -214,6 +217,13 @@ class BatchedTaskEnv:
         with torch.cuda.device(self.device):
             check(self._lib.dcm_env_status(self._h, _ptr(flags), _ptr(dec), _ptr(now), self._stream()))
         return dict(flags=flags, decisions=dec, now=now)
+
+    def episodes(self):
+        """int32[B]: episodes finished by each env since reset()."""
+        out = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.dcm_env_episodes(self._h, _ptr(out), self._stream()))
+        return out
 
     def tasks_state(self):
         B, T, dev = self.B, self.T, self.device

@@ -1020,6 +1020,14 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
                                 &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true);
+            // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
+            // the loaded instance, as k_rollout_random does between its episodes (the decision counter keeps running)
+            if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) &&
+                !(h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER))) {
+                if (log.len) for (int a = lane; a < eA; a += WAVE) log.len[(size_t)e * BA + a] = 0;
+                S.reset_state(h, lane);
+                S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
+            }
         }
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -1122,10 +1130,11 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
 }
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
-                                                    int64_t* dec_out, double* now_out) {
+                                                    int64_t* dec_out, double* now_out, int32_t* episodes_out) {
     const int e = blockIdx.x * WAVE + threadIdx.x;
     if (e >= B) return;
     const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{PA, PT}.rec_bytes());
+    if (episodes_out) episodes_out[e] = (int32_t)h->episodes;
     if (flags_out) flags_out[e] = h->flags;
     if (dec_out) dec_out[e] = (int64_t)h->d;
     if (now_out) now_out[e] = h->now;
@@ -1472,7 +1481,17 @@ int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, do
     CHECK_ENV(env);
     const int B = env->p.n_envs;
     hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
-                       env->state, B, flags_out, decisions_out, now_out);   // (layout dims: only the record pitch matters)
+                       env->state, B, flags_out, decisions_out, now_out, (int32_t*)nullptr);   // (layout dims: only the record pitch matters)
+    LAUNCH_OK();
+    return DCM_OK;
+}
+
+int dcm_env_episodes(dcm_env* env, int32_t* episodes_out, void* stream) {
+    CHECK_ENV(env);
+    if (!episodes_out) return fail(DCM_ERR_INVALID, "dcm_env_episodes: null episodes_out");
+    const int B = env->p.n_envs;
+    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
+                       env->state, B, (uint32_t*)nullptr, (int64_t*)nullptr, (double*)nullptr, episodes_out);
     LAUNCH_OK();
     return DCM_OK;
 }

@@ -69,6 +69,13 @@ typedef enum {
  * injected, dcm_observe / dcm_step take the lowest pending id as the deciding agent and no followers.
  * Honoured by dcm_reset / dcm_observe / dcm_step; dcm_rollout_random always groups by location. */
 #define DCM_PARAM_NO_GROUPING 1u
+/* dcm_params.flags: auto-reset for the lockstep API -- when a dcm_step ends an env's episode (terminal box of worker.py:87,
+ * results written to its dcm_summary row), the same call restarts the env from its loaded instance (reset + clear_decisions
+ * + the first event, exactly what dcm_rollout_random does between its episodes: the decision counter keeps running) and the
+ * fused observation is the first decision of the new episode; the env stays active.  dcm_env_episodes counts the finished
+ * episodes.  This is SURVEY.md §8(d)'s "consecutive episodes, auto-reset to the same instance" for a policy in the loop: the
+ * batch stays full instead of waiting for its longest episode.  Envs frozen by an error flag are not restarted. */
+#define DCM_PARAM_AUTO_RESET 2u
 
 typedef struct {
     int32_t n_envs;             /* B */
@@ -167,6 +174,9 @@ int dcm_summary(dcm_env *env, double *out, void *stream);
 
 /* Per-env flags (DCM_FLAG_*), decision counters and current time. Any pointer may be NULL. */
 int dcm_env_status(dcm_env *env, uint32_t *flags_out, int64_t *decisions_out, double *now_out, void *stream);
+
+/* episodes_out[B] i32: episodes finished by each env since dcm_reset (dcm_step with DCM_PARAM_AUTO_RESET, dcm_rollout_random). */
+int dcm_env_episodes(dcm_env *env, int32_t *episodes_out, void *stream);
 
 /* Per-task / per-agent state for parity tests and the per-env facade (any pointer may be NULL):
  * tasks: finished,feasible u8[B,T]; time_start,time_finish,sum_waiting_time f64[B,T]; status,n_members,n_abandoned i32[B,T]

@@ -253,3 +253,72 @@ def test_individual_selection_mode(gpu_device, oracle_lib, A, T, policy):
         ref = o.final()
         assert steps[b] == n, (b, steps[b], n)
         H.assert_final_matches(fin[b], ref, f"IS env{b}")
+
+
+def test_auto_reset_lockstep_matches_multi_episode_golden(gpu_device, golden_dir, oracle_lib):
+    """DCM_PARAM_AUTO_RESET: dcm_step restarts an env in the call that ends its episode (consecutive episodes,
+    auto-reset to the same instance, decision counter keeps running).  B = 1 against the reference-generated 3-episode golden
+    (manifest.json multi_episode), then a batch against the oracle episode by episode (d0 = decisions so far)."""
+    import json
+    import os
+    import helpers as H
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch, generate_instance
+    man = json.load(open(os.path.join(golden_dir, "manifest.json")))["multi_episode"]
+    inst = generate_instance(20, 50, man["inst_seed"])
+    seed = int(man["seed_e"])
+    env = BatchedTaskEnv(1, 20, 50, device=gpu_device, auto_reset=True)
+    env.load_instances(inst["depot"][None], inst["task_xy"][None], inst["req"][None], inst["dur"][None])
+    obs = env.reset(np.array([seed], np.uint64))
+    d, done = 0, 0
+    bounds = np.cumsum([ep["n_steps"] for ep in man["episodes"]])
+    while done < 3:
+        assert bool(obs.active[0])                                   # the env never goes idle
+        a = H.host_random_action(obs.mask[0].cpu().numpy().astype(np.uint8), seed, d)
+        obs = env.step(np.array([a], np.int32))
+        d += 1
+        n_ep = int(env.episodes()[0])
+        if n_ep > done:
+            ep = man["episodes"][done]
+            assert d == bounds[done], (done, d, bounds[done])
+            sm = env.summary().cpu().numpy()[0]
+            assert sm[0] == ep["reward"] and int(sm[1]) == ep["n_finished"]
+            for i in range(6):
+                assert sm[2 + i] == ep["metrics"][i]
+            done = n_ep
+            assert float(env.status()["now"][0]) == 0.0              # the new episode sits at its first event
+    # batch: every env against the oracle, episode after episode
+    B, A, T = 24, 12, 23
+    insts = generate_batch(B, A, T, base_seed=40)
+    seeds = env_seeds(6, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True).load_instances(**insts)
+    obs = env.reset(seeds)
+    refs = []
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T).load(insts["depot"][b], insts["task_xy"][b], insts["req"][b], insts["dur"][b])
+        r1 = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, record=False)
+        o.clear_decisions()
+        r2 = o.rollout(int(seeds[b]), r1["n_steps"], oracle_lib.POLICY_RANDOM, record=False)
+        refs.append((r1, r2))
+    dcount = np.zeros(B, np.int64)
+    seen = np.zeros(B, np.int64)
+    for _ in range(2000):
+        mk = obs.mask.cpu().numpy().astype(np.uint8)
+        act = np.array([H.host_random_action(mk[b], int(seeds[b]), int(dcount[b])) for b in range(B)], np.int32)
+        obs = env.step(act)
+        dcount += 1
+        eps = env.episodes().cpu().numpy()
+        sm = env.summary().cpu().numpy()
+        for b in np.flatnonzero(eps > seen):
+            k = int(seen[b])
+            if k < 2:
+                ref = refs[b][k]
+                total = refs[b][0]["n_steps"] + (refs[b][1]["n_steps"] if k == 1 else 0)
+                assert dcount[b] == total and sm[b, 0] == ref["reward"], (b, k)
+                for i in range(6):
+                    assert sm[b, 2 + i] == ref["metrics"][i], (b, k, i)
+        seen = np.maximum(seen, eps)
+        if (seen >= 2).all():
+            break
+    assert (seen >= 2).all() and bool(obs.active.all())
