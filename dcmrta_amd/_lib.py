@@ -24,7 +24,7 @@ FLAG_WAIT_ORDER = 128   # informational: a per-(agent, task) abandonment counter
 class DcmParams(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("n_agents", C.c_int32), ("n_tasks", C.c_int32), ("device", C.c_int32),
                 ("max_waiting_time", C.c_double), ("max_time", C.c_double), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("auto_reset_episodes", C.c_uint32)]
 
 
 class DcmError(RuntimeError):

@@ -42,7 +42,7 @@ def _ptr(t):
 
 class BatchedTaskEnv:
     def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
-                 individual_selection=False, auto_reset=False):
+                 individual_selection=False, auto_reset=False, auto_reset_episodes=0):
         self._h = None
         self._lib = _lib.load()
         self.device = torch.device(device)
@@ -58,7 +58,8 @@ class BatchedTaskEnv:
         # auto_reset: step() restarts an env from its instance in the call that ends its episode (DCM_PARAM_AUTO_RESET): the
         # batch stays full; summary() holds each env's last finished episode, episodes() counts them
         flags = (1 if individual_selection else 0) | (2 if auto_reset else 0)
-        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, flags, 0)
+        # auto_reset_episodes: an env stops restarting after that many finished episodes (0 = never)
+        p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, flags, int(auto_reset_episodes))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self._lib.dcm_create(C.byref(p), C.byref(h)))

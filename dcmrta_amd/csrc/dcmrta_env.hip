@@ -995,7 +995,8 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
-                                              uint16_t* ablog, uint32_t mode, const int32_t* sizes, unsigned char* gscr) {
+                                              uint16_t* ablog, uint32_t mode, const int32_t* sizes, unsigned char* gscr,
+                                              uint32_t max_episodes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
@@ -1023,7 +1024,8 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
             // the loaded instance, as k_rollout_random does between its episodes (the decision counter keeps running)
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) &&
-                !(h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER))) {
+                !(h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) &&
+                (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
                 if (log.len) for (int a = lane; a < eA; a += WAVE) log.len[(size_t)e * BA + a] = 0;
                 S.reset_state(h, lane);
                 S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
@@ -1446,7 +1448,8 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
 #define CALL(CA, CT, RS)                                                                                             \
     hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
-                       active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch)
+                       active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch, \
+                       env->p.auto_reset_episodes)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();

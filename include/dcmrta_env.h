@@ -74,7 +74,8 @@ typedef enum {
  * + the first event, exactly what dcm_rollout_random does between its episodes: the decision counter keeps running) and the
  * fused observation is the first decision of the new episode; the env stays active.  dcm_env_episodes counts the finished
  * episodes.  This is SURVEY.md §8(d)'s "consecutive episodes, auto-reset to the same instance" for a policy in the loop: the
- * batch stays full instead of waiting for its longest episode.  Envs frozen by an error flag are not restarted. */
+ * batch stays full instead of waiting for its longest episode.  Envs frozen by an error flag are not restarted, nor envs
+ * that have finished dcm_params.auto_reset_episodes episodes (when that is non-zero). */
 #define DCM_PARAM_AUTO_RESET 2u
 
 typedef struct {
@@ -85,7 +86,8 @@ typedef struct {
     double max_waiting_time;    /* env/task_env.py:30 (10) */
     double max_time;            /* MAX_TIME, parameters.py:18 (100) */
     uint32_t flags;             /* DCM_PARAM_* bits */
-    uint32_t reserved;
+    uint32_t auto_reset_episodes; /* with DCM_PARAM_AUTO_RESET: an env stops restarting once it has finished this many
+                                   * episodes since dcm_reset (0 = it restarts forever) */
 } dcm_params;
 
 const char *dcm_last_error(void);

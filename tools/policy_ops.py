@@ -52,3 +52,18 @@ def one_query():
     return (torch.softmax(s, -1).unsqueeze(-1) * Vc).sum(2)
 t("elementwise single-query attention", one_query)
 t("kv projection for Nq=1 block [M,128]x[128,256]", lambda: x2 @ wqkv[:, D:])
+# re-associated single-query attention: no K / V projection of the Nk tokens
+Wk3 = wqkv[:, D:2 * D].reshape(D, h, dk); Wv3 = wqkv[:, 2 * D:].reshape(D, h, dk)
+qh = q1[:, :, 0, :]                                   # B,h,dk
+def reassoc():
+    U = torch.einsum('bhk,dhk->bhd', qh, Wk3)         # B,h,D
+    s = torch.bmm(U, x.transpose(1, 2)) * (dk ** -0.5)   # B,h,N
+    a = torch.softmax(s, -1)
+    ctx = torch.bmm(a, x)                              # B,h,D
+    return torch.einsum('bhd,dhk->bhk', ctx, Wv3).reshape(B, D)
+t("re-associated single-query attention (incl. no kv proj)", reassoc)
+t("  bmm(U, x^T)", lambda: torch.bmm(torch.einsum('bhk,dhk->bhd', qh, Wk3), x.transpose(1, 2)))
+a_ = torch.softmax(torch.bmm(torch.einsum('bhk,dhk->bhd', qh, Wk3), x.transpose(1, 2)), -1)
+t("  bmm(a, x)", lambda: torch.bmm(a_, x))
+ref = F.scaled_dot_product_attention(q1, *((x2 @ wqkv[:, D:]).view(B, N, 2, h, dk).permute(2, 0, 3, 1, 4))).reshape(B, D)
+print("  max abs diff vs SDPA path:", (reassoc() - ref).abs().max().item(), "ref scale", ref.abs().max().item())
