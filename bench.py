@@ -18,7 +18,8 @@ driver.py:129-130), issued asynchronously so that it overlaps with the next pass
 
 --streams S: the rank's env block is cut into S contiguous sub-batches, each with its own handle and HIP stream.  A pass
 is then S launches; a launch lasts as long as its slowest env, and with several independent streams one sub-batch's tail
-(few live waves) overlaps with the body of the others instead of idling the machine (DESIGN.md §6 "launch tail").
+(few live waves) overlaps with the body of the others instead of idling the machine (DESIGN.md §6 "launch tail").  Default
+(--streams 0): 4 / 2 / 1 sub-batches are timed in an untimed calibration before the warm-up and the fastest is used.
 """
 import argparse
 import json
@@ -49,7 +50,7 @@ CONFIGS = {
     "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]"),
     "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]"),
 }
-DEFAULT_STREAMS = 4
+AUTO_STREAM_CANDIDATES = (4, 2, 1)   # --streams 0: pick the fastest of these in an untimed calibration before the warm-up
 
 
 def usable_cores():
@@ -155,7 +156,8 @@ def main():
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--tasks", type=int, default=None)
     ap.add_argument("--episodes", type=int, default=None, help="consecutive episodes per env per pass")
-    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS, help="sub-batches (HIP streams) per GPU")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batches (HIP streams) per GPU; 0 = calibrate 4 / 2 / 1 before the warm-up and keep the fastest")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
@@ -176,13 +178,44 @@ def main():
         n_total = cfg["envs"]
         first, hi = shard_range(n_total, ctx.rank, ctx.world)
         B = hi - first
-    S = max(1, min(args.streams, B))
     main_stream = torch.cuda.current_stream(dev)
-    subs = []
-    for s in range(S):
-        lo, hi = shard_range(B, s, S)
-        subs.append(SubBatch(first + lo, hi - lo, A, T, dev, main_stream if S == 1 else torch.cuda.Stream(device=dev)))
-    torch.cuda.synchronize(dev)
+    # one set of side streams for the calibration AND the run: which hardware queue a stream lands on is decided by the runtime
+    # when the stream is created / first used, so a calibration on other stream objects would not describe the run
+    side_streams = [torch.cuda.Stream(device=dev) for _ in range(max(max(AUTO_STREAM_CANDIDATES), args.streams))]
+
+    def make_subs(S):
+        out = []
+        for k in range(S):
+            lo, hi = shard_range(B, k, S)
+            out.append(SubBatch(first + lo, hi - lo, A, T, dev, main_stream if S == 1 else side_streams[k]))
+        torch.cuda.synchronize(dev)
+        return out
+
+    def calibrate(cand, passes=6):
+        """Untimed: seconds per pass of `cand` sub-batches (one warm pass, then `passes` passes back to back)."""
+        subs_c = make_subs(cand)
+        for timed in (False, True):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(passes if timed else 1):
+                for sb in subs_c:
+                    with torch.cuda.stream(sb.stream):
+                        sb.env.rollout_random(episodes=EP, write_obs=not args.no_obs)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / passes
+        for sb in subs_c:
+            sb.env.close()
+        return dt
+
+    calibration = None
+    if args.streams > 0:
+        S = max(1, min(args.streams, B))
+    else:
+        # how many streams pay off depends on how the runtime maps them onto hardware queues (see GPU_MAX_HW_QUEUES above):
+        # measure instead of assuming
+        calibration = {c: calibrate(c) for c in AUTO_STREAM_CANDIDATES if c <= B}
+        S = min(calibration, key=calibration.get)
+    subs = make_subs(S)
     returns = [torch.empty((B,), dtype=torch.float64, device=dev) for _ in range(2)]   # double-buffered per-pass returns
 
     def one_pass(k, timed):
@@ -294,6 +327,7 @@ def main():
                                 f"({cfg['label']})"),
                    "envs_per_gpu": B, "envs_total": n_total, "agents": A, "tasks": T, "episodes_per_step": EP,
                    "decisions_per_step_per_gpu": dec_per_step, "decisions_in_warmup_per_gpu": warm_steps, "streams_per_gpu": S,
+                   "stream_calibration_ms_per_pass": ({str(k): v * 1e3 for k, v in calibration.items()} if calibration else None),
                    "sharding": f"env batch x{ctx.world}, no data-path collective"
                                + (", one async all-gather of the episode returns per pass" if ctx.active else ""),
                    "dist_backend": ctx.backend or None},
