@@ -71,6 +71,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise DcmError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64; load it FIRST so that this library binds to the same HIP runtime instance
+        # the tensors come from (loaded the other way round the process ends up with two runtimes and dcm_create sees no device)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
