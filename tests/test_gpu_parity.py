@@ -133,9 +133,11 @@ def test_rollout_kernel_matches_oracle_20A50T(gpu_device, oracle_lib):
         H.assert_final_matches(fin[b], ref, f"env{b}")
 
 
-@pytest.mark.parametrize("A,T,B", [(5, 8, 8), (1, 1, 4), (13, 37, 8), (64, 64, 4), (70, 130, 4), (50, 200, 6), (100, 500, 2)])
+@pytest.mark.parametrize("A,T,B", [(5, 8, 8), (1, 1, 4), (13, 37, 8), (64, 64, 4), (21, 51, 6), (70, 130, 4), (50, 200, 6), (100, 500, 2),
+                                   (128, 1023, 2)])
 def test_rollout_kernel_matches_oracle_shapes(gpu_device, oracle_lib, A, T, B):
-    """Ragged / edge shapes: 1 agent 1 task, exactly one wave of agents, A > 64 (two mask words), BASELINE configs 4-5 sizes."""
+    """Edge shapes: 1 agent 1 task, exactly one wave of agents, the <64,64> layout class, A > 64 (two mask words), BASELINE
+    configs 4-5 sizes, and the maximum the ABI accepts (128 agents, 1023 tasks: a 104 KB record, one workgroup per CU)."""
     from dcmrta_amd.choice import env_seeds
     from dcmrta_amd.instances import generate_batch
     inst = generate_batch(B, A, T, base_seed=500 + A)
