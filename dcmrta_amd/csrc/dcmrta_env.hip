@@ -853,14 +853,10 @@ struct Sim {
                     pos = n++;
                     ids |= (uint64_t)(uint32_t)m << (8 * pos);                // bytes above n are always zero
                 }
-                double av = 0.0;                                              // arrival computed by agent m's lane above
+                // the arrival was computed by agent m's own lane above: that lane stores it (no readlane round trip through
+                // the scalar unit, and the store does not wait for the sqrt chain of the other members)
 #pragma unroll
-                for (int i = 0; i < NAW; i++) if (i == (m >> 6)) {
-                    const int lo = __builtin_amdgcn_readlane(__double2loint(arrv[i]), m & 63);
-                    const int hi = __builtin_amdgcn_readlane(__double2hiint(arrv[i]), m & 63);
-                    av = __hiloint2double(hi, lo);
-                }
-                if (lane == 0) marr()[pos * PT() + k] = av;
+                for (int i = 0; i < NAW; i++) if (i * WAVE + lane == m) marr()[pos * PT() + k] = arrv[i];
             }
             if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
@@ -1107,7 +1103,8 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
         //  splits the hot block and was measured 2.3 % slower)
         while (!(h.flags & DCM_FLAG_DONE) && left != 0) {
             AMask gm;
-            const uint64_t k1 = mix64(gd);
+            const uint64_t k1 = mix64(gd);   // (computing the next decision's key early, under the LDS latency of apply, measured
+                                             //  0.9 % SLOWER: two more live registers across the whole decision)
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
             PH_MARK(0);
