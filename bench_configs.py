@@ -9,6 +9,7 @@ Prints one JSON line per config (1 GPU; config 4's sharded variant is bench.py -
   2g  the same loop as eager launches vs ONE HIP graph per decision
   3   4096 envs 20A/50T, attention policy (stock PyTorch-ROCm) + HIP env step: eager fp32 / HIP graph fp32 / HIP graph with a
       bf16 and an fp16 shadow of the net, policy : env time split, end-to-end steps/s
+  7   runner level: BatchedRunner.job (sampled episode + greedy twin + experience) at 256 / 4096 envs
   6   runtime-shape path: the persistent kernel and k_step at 4096 x 15A/35T, 4096 x 20A/49T and a ragged (10-20) x (20-50)
       batch next to the exact 20A/50T instantiation
   4   8192 envs/GPU 50A/200T random-policy rollout (the per-GPU shard of 65536 envs over 8 GPUs)
@@ -307,10 +308,35 @@ def config5(B=1024, A=100, T=500):
                 reference_python="~400 agent-steps/s at 20A/50T (BASELINE.md)")
 
 
+def config7(A=20, T=50):
+    """Runner level (what driver.py consumes): BatchedRunner.job = one sampled + one greedy episode per env + the experience
+    buffers (runner.py:58-71, worker.py:41-112), decisions recorded per second of job wall time."""
+    from dcmrta_amd.runner import BatchedRunner
+    rows = {}
+    for B, prec in ((256, "fp32"), (4096, "fp32"), (4096, "fp16")):
+        torch.manual_seed(0)
+        r = BatchedRunner(n_envs=B, device=DEV, rollout_precision=prec)
+        w = {k: v.clone() for k, v in r.get_weights().items()}
+        r.job(w, w, 0, A, T)                                   # captures the graphs
+        sync(); t0 = time.perf_counter()
+        res, metrics, info = r.job(w, w, 1, A, T)
+        sync(); wall = time.perf_counter() - t0
+        n = res[0].shape[0]
+        t0 = time.perf_counter()
+        lists = [list(x.unbind(0)) if isinstance(x, torch.Tensor) else x for x in res]
+        t_lists = time.perf_counter() - t0
+        rows[f"B{B}_{prec}"] = dict(recorded_decisions=n, job_seconds=wall, recorded_decisions_per_s=n / wall,
+                                    sim_decisions_per_s=(n + int(r.last["greedy_rec"]["active"].sum()) if r.last["greedy_rec"] else 2 * n) / wall,
+                                    unbind_to_lists_seconds=t_lists, makespan=metrics["makespan"])
+        r.close()
+    return dict(config=7, workload=f"BatchedRunner.job at {A}A/{T}T (sampled episode + greedy twin + 9-slot experience per env)", **rows,
+                reference_python="~80 recorded decisions/s per Ray worker process (BASELINE.md)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
     a = ap.parse_args()
-    table = {"1": config1, "2l": config2_lockstep, "2g": config2_graph, "3": config3, "4": config4, "5": config5, "6": config6}
+    table = {"1": config1, "2l": config2_lockstep, "2g": config2_graph, "3": config3, "4": config4, "5": config5, "6": config6, "7": config7}
     for k in (table if a.config == "all" else [a.config]):
         print(json.dumps(table[k]()), flush=True)
