@@ -207,6 +207,20 @@ def config3(B=4096, A=20, T=50):
                                                     ms_per_batched_step=wall / batched * 1e3, active_fraction=dec / (batched * B),
                                                     episodes=int(env3.episodes().sum()))
     env3.close()
+    # + compaction: the policy runs only on the envs that still have an episode to play (one graph per bucket size)
+    BUCKETS = (1.0, 0.75, 0.5, 0.375, 0.25, 0.125, 0.0625)
+    for key, kw in (("graph_fp16_tuned_compacted", {}),
+                    ("graph_fp16_tuned_3_episodes_auto_reset_compacted", dict(auto_reset=True, auto_reset_episodes=3))):
+        envc = BatchedTaskEnv(B, A, T, device=DEV, **kw).load_instances(**inst)
+        g = GraphedRollout(envc, sampler(m16), check_every=4, buckets=BUCKETS)
+        g.run(seeds)
+        sync(); t0 = time.perf_counter()
+        summary, batched = g.run(seeds)
+        sync(); wall = time.perf_counter() - t0
+        dec = int(envc.status()["decisions"].sum())
+        rows[key] = dict(steps_per_s_end_to_end=dec / wall, batched_steps=batched, ms_per_batched_step=wall / batched * 1e3,
+                         active_fraction=dec / (batched * B), bucket_steps={str(k): v for k, v in g.bucket_steps.items()})
+        envc.close()
     envs = BatchedTaskEnv(B, A, T, device=DEV, auto_reset=True).load_instances(**inst)
     g = GraphedRollout(envs, sampler(m16), check_every=8)
     g.capture(seeds)

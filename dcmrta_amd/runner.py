@@ -38,11 +38,13 @@ class EnvError(RuntimeError):
 
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
-                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8):
+                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets=None):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
-        steps (default 6 (A + T) + 64, ~3x the longest episode seen at the reference's constants)."""
+        steps (default 6 (A + T) + 64, ~3x the longest episode seen at the reference's constants).  buckets: e.g.
+        (1.0, 0.5, 0.25) -- the policy runs only on the envs still active once half / three quarters of the episodes are
+        over (GraphedRollout compaction; worthwhile when the forward is much more expensive than the env step)."""
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
@@ -50,6 +52,7 @@ class BatchedRunner:
         self.max_steps = None if max_steps is None else int(max_steps)
         self.gamma = float(gamma)            # GAMMA, parameters.py:6 (1 in the reference)
         self.check_every, self.use_graph = int(check_every), bool(use_graph)
+        self.buckets = tuple(buckets) if buckets else None
         if net_factory is None:
             from .policy import AttentionNet
             net_factory = lambda: AttentionNet(6, 5, 128)  # AGENT_INPUT_DIM, TASK_INPUT_DIM, EMBEDDING_DIM (parameters.py:29-31)
@@ -151,7 +154,8 @@ class BatchedRunner:
         key = (id(net), mode, bool(record))
         g = slot["graphs"].get(key)
         if g is None:
-            g = GraphedRollout(env, policy, check_every=self.check_every, record=record, capacity=self.max_steps)
+            g = GraphedRollout(env, policy, check_every=self.check_every, record=record, capacity=self.max_steps,
+                               buckets=self.buckets)
             slot["graphs"][key] = g
         summary, n = g.run(seeds)
         rec = {k: v[:n] for k, v in g.rec.items()} if record else None

@@ -48,6 +48,42 @@ def test_graph_replay_matches_oracle(gpu_device, oracle_lib):
     assert torch.equal(summary4, summary)
 
 
+def test_compacted_policy_buckets_match_oracle(gpu_device, oracle_lib):
+    """buckets: the policy runs only on the envs still active (gathered rows, one graph per bucket size).  Same episodes as
+    the full-batch loop, and they replay through the oracle; the small buckets really are used once envs finish."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.graph_rollout import GraphedRollout
+    from dcmrta_amd.instances import generate_batch
+    from dcmrta_amd.instances import generate_batch_ranges
+    B, A, T = 64, 20, 50
+    inst = generate_batch_ranges(range(900, 900 + B), (4, 20), (5, 50))       # very different sizes -> very different lengths
+    seeds = env_seeds(9, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    full = GraphedRollout(env, first_valid, check_every=4, record=True)
+    s_full, n_full = full.run(seeds)
+    rec_full = {k: v[:n_full].clone() for k, v in full.rec.items()}
+    g = GraphedRollout(env, first_valid, check_every=4, record=True, buckets=(1.0, 0.5, 0.25, 0.125))
+    s_b, n_b = g.run(seeds)
+    assert torch.equal(s_b, s_full) and n_b == n_full
+    rec = {k: v[:n_b] for k, v in g.rec.items()}
+    act = rec["active"]
+    assert torch.equal(act, rec_full["active"])
+    for k in ("agents", "tasks", "mask", "leader"):
+        assert torch.equal(rec[k][act], rec_full[k][act]), k
+    assert torch.equal(rec["action"][act], rec_full["action"][act])
+    assert g.bucket_steps[B] > 0 and sum(v for n, v in g.bucket_steps.items() if n < B) > 0, g.bucket_steps
+    _replay_recorded(oracle_lib, rec, s_b.cpu().numpy(), inst, seeds, A, T, n_agents=inst["n_agents"], n_tasks=inst["n_tasks"])
+    # with auto-reset and an episode limit the active set also only shrinks: 2 episodes per env, compacted
+    env2 = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True, auto_reset_episodes=2).load_instances(**inst)
+    g2 = GraphedRollout(env2, first_valid, check_every=4, buckets=(1.0, 0.5, 0.25))
+    g2.run(seeds)
+    assert (env2.episodes() == 2).all()
+    ref_env = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True, auto_reset_episodes=2).load_instances(**inst)
+    GraphedRollout(ref_env, first_valid, check_every=4).run(seeds)
+    assert torch.equal(env2.summary(), ref_env.summary()) and torch.equal(env2.status()["decisions"], ref_env.status()["decisions"])
+
+
 def test_record_capacity_is_enforced(gpu_device):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.choice import env_seeds
