@@ -16,33 +16,61 @@ def _mk(B, A, T, dev, seed=0):
     return BatchedTaskEnv(B, A, T, device=dev).load_instances(**inst), inst
 
 
-def test_observe_is_pure_and_matches_fused_observe(gpu_device):
+def _oracle_random(oracle_lib, inst, seeds, A, T, b, record):
+    o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+    return o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, record=record)
+
+
+def test_observe_is_pure_and_matches_fused_observe(gpu_device, oracle_lib):
+    """dcm_observe is a pure function of the state: it returns what the fused observe of dcm_step wrote, twice -- and both
+    are the oracle's record of that decision (protocol-random actions chosen on the host)."""
     from dcmrta_amd.choice import env_seeds
-    env, _ = _mk(32, 20, 50, gpu_device)
-    obs = env.reset(env_seeds(1, 0, 32))
-    for _ in range(15):
+    B, A, T = 32, 20, 50
+    env, inst = _mk(B, A, T, gpu_device)
+    seeds = env_seeds(1, 0, B)
+    refs = [_oracle_random(oracle_lib, inst, seeds, A, T, b, True) for b in range(B)]
+    obs = env.reset(seeds)
+    for d in range(15):
         a = [t.clone() for t in (obs.agents, obs.tasks, obs.mask, obs.leader, obs.active)]
-        again = env.observe()
-        for x, y in zip(a, (again.agents, again.tasks, again.mask, again.leader, again.active)):
-            assert torch.equal(x, y)
-        act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()
+        for again in (env.observe(), env.observe()):
+            for x, y in zip(a, (again.agents, again.tasks, again.mask, again.leader, again.active)):
+                assert torch.equal(x, y)
+        ag, tk, mk, ld = (t.cpu().numpy() for t in a[:4])
+        for b in range(B):
+            r = refs[b]
+            assert ld[b] == r["leader"][d] and np.array_equal(ag[b], r["agents_obs"][d]) and np.array_equal(tk[b], r["tasks_obs"][d])
+            assert np.array_equal(mk[b].astype(np.uint8), r["mask"][d])
+        act = np.array([H.host_random_action(mk[b].astype(np.uint8), int(seeds[b]), d) for b in range(B)], np.int32)
+        assert all(act[b] == refs[b]["action"][d] for b in range(B))
         obs = env.step(act)
 
 
-def test_clone_restore_replays_identically(gpu_device):
-    """Greedy-twin use of worker.py:33,89: snapshot, run, restore, run again -> same episode."""
+def test_clone_restore_replays_identically(gpu_device, oracle_lib):
+    """Greedy-twin use of worker.py:33,89: snapshot mid-episode, play the episode out, restore, play it out again -> the same
+    episode both times, and it is the oracle's episode (the first 7 decisions through the lockstep API, the rest in the
+    persistent kernel, all from the shared choice protocol)."""
     from dcmrta_amd.choice import env_seeds
-    env, _ = _mk(64, 20, 50, gpu_device, seed=5)
-    env.reset(env_seeds(2, 0, 64), observe=False)
-    for _ in range(7):
-        obs = env.observe()
-        env.step(torch.multinomial((~obs.mask).float(), 1).squeeze(1).int(), observe=False)
+    B, A, T = 64, 20, 50
+    env, inst = _mk(B, A, T, gpu_device, seed=5)
+    seeds = env_seeds(2, 0, B)
+    refs = [_oracle_random(oracle_lib, inst, seeds, A, T, b, False) for b in range(B)]
+    obs = env.reset(seeds)
+    for d in range(7):
+        mk = obs.mask.cpu().numpy().astype(np.uint8)
+        obs = env.step(np.array([H.host_random_action(mk[b], int(seeds[b]), d) for b in range(B)], np.int32))
     snap = env.clone_state()
     s1 = env.rollout_random(1).clone()
     r1 = env.summary().clone()
+    f1 = H.gpu_final(env)
     env.restore_state(snap)
+    assert (env.status()["decisions"] == 7).all()
     s2 = env.rollout_random(1)
     assert torch.equal(s1, s2) and torch.equal(r1, env.summary())
+    f2 = H.gpu_final(env)
+    for b in range(B):
+        assert int(s1[b]) + 7 == refs[b]["n_steps"], b
+        H.assert_final_matches(f1[b], refs[b], f"env{b} first run")
+        H.assert_final_matches(f2[b], refs[b], f"env{b} after restore")
 
 
 def test_error_flags_freeze_only_the_offending_env(gpu_device):
