@@ -334,3 +334,20 @@ def test_learner_step_on_runner_output(gpu_device):
     with pytest.raises(Exception):
         ray.get(bad.job.remote({}, {}, 0, 5, 8))
     ray.kill(bad)
+
+
+def test_rl_test_example_script(gpu_device, tmp_path):
+    """examples/rl_test.py = RL_test.py:1-51 batched: both METHODs over the shipped test-set instances, CSV in the reference's
+    column layout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for method in ("LF", "IA"):
+        out = tmp_path / f"REINFORCE_{method}.csv"
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "rl_test.py"), "--method", method, "--out", str(out)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows = out.read_text().strip().splitlines()
+        assert rows[0] == ",success_rate,makespan,time_cost,waiting_time,travel_dist,efficiency" and len(rows) == 51
+        vals = np.array([[float(x) for x in l.split(",")[1:]] for l in rows[1:]])
+        assert (vals[:, 0] >= 0).all() and (vals[:, 0] <= 1).all() and (vals[:, 1] > 0).all()
