@@ -350,3 +350,37 @@ def test_auto_reset_lockstep_matches_multi_episode_golden(gpu_device, golden_dir
         if (seen >= 2).all():
             break
     assert (seen >= 2).all() and bool(obs.active.all())
+
+
+def test_auto_reset_with_individual_selection(gpu_device):
+    """DCM_PARAM_AUTO_RESET | DCM_PARAM_NO_GROUPING: individual selection draws nothing from the choice protocol (lowest pending
+    id decides, alone), so under a deterministic policy every episode of an env repeats the first one exactly -- which is the
+    episode the same env plays without auto-reset (itself checked against the reference loop in
+    test_individual_selection_mode)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 12, 9, 17
+    inst = generate_batch(B, A, T, base_seed=3)
+    seeds = env_seeds(4, 0, B)
+    first_valid = lambda obs: torch.argmax((~obs.mask).to(torch.int32), dim=1).int()
+    ref = BatchedTaskEnv(B, A, T, device=gpu_device, individual_selection=True).load_instances(**inst)
+    obs = ref.reset(seeds)
+    while bool(obs.active.any()):
+        obs = ref.step(first_valid(obs))
+    want, n1 = ref.summary().clone(), ref.status()["decisions"].clone()
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, individual_selection=True, auto_reset=True,
+                         auto_reset_episodes=3).load_instances(**inst)
+    obs = env.reset(seeds)
+    seen = torch.zeros(B, dtype=torch.int32, device=gpu_device)
+    for _ in range(5000):
+        if not bool(obs.active.any()):
+            break
+        obs = env.step(first_valid(obs))
+        eps = env.episodes()
+        newly = eps > seen
+        if bool(newly.any()):
+            assert torch.equal(env.summary()[newly], want[newly])          # every finished episode equals the first one
+            seen = eps.clone()
+    assert (env.episodes() == 3).all() and not bool(obs.active.any())
+    assert torch.equal(env.status()["decisions"], 3 * n1) and torch.equal(env.summary(), want)
