@@ -104,21 +104,32 @@ class DistContext:
         return out
 
     def verify_gather(self, gathered, local_returns, first):
-        """Raise unless `gathered` is the rank-major concatenation of every rank's local vector ON EVERY RANK: this rank's
-        block sits at [first, first + B_local) bit for bit, and all ranks hold the same vector (min == max over ranks of a
+        """Raise -- on EVERY rank, after the same collectives, so that no rank is left waiting in one -- unless `gathered` is
+        the rank-major concatenation of every rank's local vector on every rank: each rank finds its own block at
+        [first, first + B_local) bit for bit, and all ranks hold the same vector (min == max over ranks of a
         position-weighted checksum of the raw bits)."""
         g = gathered.contiguous().view(torch.int64) if gathered.dtype == torch.float64 else gathered
         l = local_returns.contiguous().view(torch.int64) if local_returns.dtype == torch.float64 else local_returns
-        if not torch.equal(g[first:first + l.numel()].cpu(), l.cpu()):
-            raise RuntimeError(f"rank {self.rank}: gathered returns do not hold this rank's block at offset {first}")
+        own_ok = bool(torch.equal(g[first:first + l.numel()].cpu(), l.cpu()))
+        same = True
         if self._active():
             w = torch.arange(1, g.numel() + 1, dtype=torch.int64, device=g.device)
-            h = ((g.to(torch.int64) >> 12) * w).sum().to(torch.float64).reshape(1).to(self._coll_device())
-            lo, hi = h.clone(), h.clone()
+            h = float(((g.to(torch.int64) >> 12) * w).sum().to(torch.float64))
+            dev = self._coll_device()
+            lo = torch.tensor([h, 1.0 if own_ok else 0.0], dtype=torch.float64, device=dev)
+            hi = lo.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if float(lo) != float(hi):
-                raise RuntimeError("ranks hold different gathered return vectors")
+            same = float(lo[0]) == float(hi[0])
+            all_own_ok = float(lo[1]) == 1.0
+        else:
+            all_own_ok = own_ok
+        if not own_ok:
+            raise RuntimeError(f"rank {self.rank}: gathered returns do not hold this rank's block at offset {first}")
+        if not all_own_ok:
+            raise RuntimeError(f"rank {self.rank}: another rank does not find its block in its gathered returns")
+        if not same:
+            raise RuntimeError("ranks hold different gathered return vectors")
         return True
 
     def max_over_ranks(self, x):

@@ -34,11 +34,20 @@ def _worker(rank, world, port, n_total, q):
     inst = generate_batch(hi - lo, 5, 8, base_seed=11, first=lo)
     seeds = env_seeds(3, lo, hi - lo)
     _, reward, steps, _ = oracle.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"], seeds, 5)
-    gathered = ctx.all_gather_returns(torch.from_numpy(reward))
+    gathered = ctx.all_gather_returns(torch.from_numpy(reward), n_total=n_total)    # uneven blocks are padded and trimmed
+    ctx.verify_gather(gathered, torch.from_numpy(reward), lo)                       # own block in place + all ranks agree
+    bad = gathered.clone()
+    bad[(hi + 1) % n_total] += 1.0 if rank == 0 else 0.0     # rank 0 holds a different vector (outside its own block)
+    mismatch_detected = 0
+    for wrong in (bad, gathered.roll(1) if rank == 1 else gathered):                 # ... and rank 1 a vector without its own block
+        try:
+            ctx.verify_gather(wrong, torch.from_numpy(reward), lo)
+        except RuntimeError:
+            mismatch_detected += 1        # raised on BOTH ranks each time: nobody is left waiting in a collective
     total = ctx.sum_over_ranks(int(steps.sum()))
     tmax = ctx.max_over_ranks(float(rank + 1))
     ctx.barrier()
-    q.put((rank, gathered.numpy().copy(), total, tmax, (lo, hi)))
+    q.put((rank, gathered.numpy().copy(), total, tmax, (lo, hi), mismatch_detected))
     ctx.shutdown()
 
 
@@ -53,8 +62,9 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_all_gather_returns_world2(oracle_lib):
-    world, n_total = 2, 12
+@pytest.mark.parametrize("n_total", [12, 13])
+def test_all_gather_returns_world2(oracle_lib, n_total):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -71,8 +81,9 @@ def test_all_gather_returns_world2(oracle_lib):
     inst = generate_batch(n_total, 5, 8, base_seed=11)
     _, reward, steps, _ = oracle_lib.batch_rollout(inst["depot"], inst["task_xy"], inst["req"], inst["dur"],
                                                    env_seeds(3, 0, n_total), 5)
-    for rank, gathered, total, tmax, (lo, hi) in res:
+    for rank, gathered, total, tmax, (lo, hi), mismatch_detected in res:
+        assert mismatch_detected == 2, rank                                          # a corrupted vector is refused on every rank
         assert np.array_equal(gathered, reward), rank   # every rank holds the full return vector, rank-major
         assert total == int(steps.sum())
         assert tmax == float(world)
-    assert sorted(r[4] for r in res) == [(0, 6), (6, 12)]
+    assert sorted(r[4] for r in res) == ([(0, 6), (6, 12)] if n_total == 12 else [(0, 7), (7, 13)])
