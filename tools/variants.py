@@ -45,13 +45,17 @@ if os.environ.get("VARIANTS_PMC"):   # per-decision instruction counts of k_roll
         d = os.path.join(out, f"pmc_{name}")
         shutil.rmtree(d, ignore_errors=True)
         env = dict(os.environ, DCMRTA_HIP_LIB=so, TMPDIR="/tmp")
-        subprocess.run(["rocprofv3", "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
-                        "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "x", "--",
-                        "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, cwd="/tmp")
+        o = subprocess.run(["rocprofv3", "--pmc", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
+                            "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "x", "--",
+                            "python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                            "--no-lockstep-probe", "--streams", "1"],
+                           env=env, capture_output=True, text=True, cwd="/tmp")
+        line = [l for l in o.stdout.splitlines() if l.startswith("{")]
+        cfg = json.loads(line[-1])["config"] if line else None
+        decisions = (cfg["decisions_per_step_per_gpu"] * 5 + cfg["decisions_in_warmup_per_gpu"]) if cfg else float("nan")
         agg = collections.defaultdict(list)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if "k_rollout" in r["Kernel_Name"]:
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        print(name, {k: round(sum(v) / len(v) / 490700.0, 1) for k, v in sorted(agg.items())})
+        print(name, {k: round(sum(v) / decisions, 1) for k, v in sorted(agg.items())})
