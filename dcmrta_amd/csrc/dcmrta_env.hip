@@ -188,7 +188,11 @@ struct Sim {
     // tasks for np.all(feasible) :279.
     static constexpr bool INC = (CT == 0 || CT > WAVE);
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + L().aux() + 8); }
-    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1) const {
+    // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..M member-arrival row j,
+    // bit 6 member ids, bit 7 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
+    static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_IDS = 1u << 6, DIRTY_NAB = 1u << 7, DIRTY_ALL = 0xFFu;
+    __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + L().aux() + 24); }
+    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1, bool track = false) const {
         const double now = h.now, mwt = P.mwt;
         const int T_ = T(), PT_ = PT();
         bool allf = true, touched = false;
@@ -216,7 +220,7 @@ struct Sim {
             // built inside this rare divergent branch.
             const bool any_drop = !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
             if (!feas0) {
-                if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; }  // :256-258
+                if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; if (track) atomicOr(dirty(), DIRTY_TIMES); }  // :256-258
                 int nn = n;
                 if (any_drop) {  // rare: compact the surviving members in order
                     uint32_t spread = 0, q1 = 0;
@@ -253,6 +257,7 @@ struct Sim {
                     mids()[t] = nids;
                     tnab()[t] += (uint32_t)(n - k);
                     nn = k;
+                    if (track) atomicOr(dirty(), DIRTY_ALL & ~DIRTY_TIMES);   // slots compacted: every arrival row, ids, counts
                 }
                 info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
             } else {
@@ -506,7 +511,7 @@ struct Sim {
     // no_grouping: every deciding agent forms ONE group (individual selection, worker.py:159-198 iterates the deciders without
     // get_unique_group); lockstep API only.
     __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
-                                            bool no_grouping = false) const {
+                                            bool no_grouping = false, bool track = false) const {
         const int A_ = A();
         for (;;) {
             WSYNC();
@@ -603,7 +608,7 @@ struct Sim {
             }
             WSYNC();
             PH_MARK(6);
-            task_update(h, P, lane);                                          // worker.py:50
+            task_update(h, P, lane, -1, track);                               // worker.py:50
             WSYNC();
             PH_MARK(7);
             agent_update(h, P, lane);                                         // worker.py:51
@@ -750,7 +755,7 @@ struct Sim {
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
                                                       const RouteLog* log = nullptr, int log_row = 0,
                                                       bool no_grouping = false, bool check_mask = false,
-                                                      bool incremental = false) const {
+                                                      bool incremental = false, bool track = false) const {
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         if (check_mask && action > 0) {
@@ -857,13 +862,14 @@ struct Sim {
                 // the scalar unit, and the store does not wait for the sqrt chain of the other members)
 #pragma unroll
                 for (int i = 0; i < NAW; i++) if (i * WAVE + lane == m) marr()[pos * PT() + k] = arrv[i];
+                if (track && lane == 0) *dirty() |= (2u << pos) | DIRTY_IDS;
             }
             if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
         h.d += 1;
         WSYNC();
         PH_MARK(3);
-        task_update(h, P, lane, incremental ? (action > 0 ? action - 1 : -2) : -1);   // worker.py:74
+        task_update(h, P, lane, incremental ? (action > 0 ? action - 1 : -2) : -1, track);   // worker.py:74
         WSYNC();
         PH_MARK(4);
         agent_update(h, P, lane);                                             // worker.py:76
@@ -871,7 +877,7 @@ struct Sim {
         PH_MARK(5);
         if (rlen > 0) return;                                                 // worker.py:53 same group, next leader
         if (h.cur_group < h.n_groups) { h.cur_group++; return; }              // worker.py:52 next group
-        advance(h, P, lane, row PH_PASS, no_grouping);                        // worker.py:85 -> :45
+        advance(h, P, lane, row PH_PASS, no_grouping, track);                 // worker.py:85 -> :45
         PH_MARK(9);
     }
 
@@ -1004,6 +1010,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     copy16_in(smem, rec, L.rec_bytes(), lane);
     S.set_ablog(ablog, e, BA, BT, lane);
+    if (lane == 0) *S.dirty() = 0;
     WSYNC();
     Hdr h = load_hdr(smem);
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
@@ -1016,7 +1023,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true);
+                                &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true, false, true);
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
             // the loaded instance, as k_rollout_random does between its episodes (the decision counter keeps running)
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) &&
@@ -1024,6 +1031,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
                 if (log.len) for (int a = lane; a < eA; a += WAVE) log.len[(size_t)e * BA + a] = 0;
                 S.reset_state(h, lane);
+                if (lane == 0) *S.dirty() = Sim<CA, CT, RS>::DIRTY_ALL;
                 S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
             }
         }
@@ -1048,7 +1056,25 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         WSYNC();
         store_hdr(h, lane);
         WSYNC();
-        copy16(rec, smem, L.mut_bytes(), lane);
+        // Write back what this step can have changed: the header and the agent arrays always, status words always, and of
+        // the other task sections only those marked dirty (one decision typically touches one member-arrival row, the id
+        // word of one task and -- when a task became feasible -- the two time arrays: ~2.4 of the 4.6 KB at 20A/50T).
+        // Ranges are widened to 16-byte boundaries; the bytes around them are unchanged copies of what HBM already holds.
+        const uint32_t dm = uni(*S.dirty());
+        auto put = [&](uint32_t lo, uint32_t hi) {     // [lo, hi) of the record
+            lo &= ~15u; hi = (hi + 15u) & ~15u;
+            copy16(rec + lo, smem + lo, hi - lo, lane);
+        };
+        const uint32_t Tn = (uint32_t)S.PT();
+        put(0, L.tb());                                                               // header + agent arrays
+        if (dm & Sim<CA, CT, RS>::DIRTY_TIMES) put(L.ts(), L.marr());                 // time_start, time_finish
+        if ((dm & 0x3Eu) == 0x3Eu) put(L.marr(), L.mids());
+        else {
+#pragma unroll
+            for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+        }
+        if (dm & Sim<CA, CT, RS>::DIRTY_IDS) put(L.mids(), L.tinfo());
+        put(L.tinfo(), (dm & Sim<CA, CT, RS>::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
     }
 }
 
