@@ -41,13 +41,14 @@ class GraphedRollout:
                             leader=torch.zeros((S, B), dtype=torch.int64, device=dev),
                             active=torch.zeros((S, B), dtype=torch.bool, device=dev))
             self.slot = torch.zeros((1,), dtype=torch.int64, device=dev)      # device-side step counter
+        buckets = tuple(buckets) if buckets else (1.0,)
+        if float(buckets[0]) != 1.0:
+            raise ValueError("buckets must start with 1.0 (the full batch)")
         sizes = [B]
-        for f in (buckets or ())[1:] if buckets else ():
+        for f in buckets[1:]:
             n = max(1, int(round(B * float(f))))
             if n < sizes[-1]:
                 sizes.append(n)
-        if buckets and float(buckets[0]) != 1.0:
-            raise ValueError("buckets must start with 1.0 (the full batch)")
         self.sizes = sizes                                                     # descending; sizes[0] == B
         self.idx = {n: torch.arange(n, dtype=torch.int64, device=dev) for n in sizes[1:]}   # static gather indices
         self.graphs = {}
