@@ -217,10 +217,18 @@ def main():
         S = min(calibration, key=calibration.get)
     subs = make_subs(S)
     returns = [torch.empty((B,), dtype=torch.float64, device=dev) for _ in range(2)]   # double-buffered per-pass returns
+    in_flight = [None, None]          # the gather still reading returns[i], if any
 
     def one_pass(k, timed):
         """Every sub-batch plays its episodes (one persistent launch each); N > 1: exchange the episode returns."""
         done = []
+        free = None
+        if ctx.active and in_flight[k & 1] is not None:
+            # the gather of pass k-2 reads the buffer this pass writes: order the sub-batch streams after it (the collective
+            # runs on RCCL's stream; work.wait() makes the main stream wait for it, the event hands that on)
+            in_flight[k & 1].wait()
+            free = torch.cuda.Event()
+            free.record(main_stream)
         for sb in subs:
             with torch.cuda.stream(sb.stream):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,6 +242,8 @@ def main():
                     sb.warm.append(steps)
                 if ctx.active:
                     lo = sb.first - first
+                    if free is not None:
+                        sb.stream.wait_event(free)
                     returns[k & 1][lo:lo + sb.B].copy_(sb.env.summary()[:, 0])
                     d = torch.cuda.Event()
                     d.record()
@@ -241,8 +251,10 @@ def main():
         if ctx.active:
             for d in done:
                 main_stream.wait_event(d)
-            # per-episode return exchange on RCCL's stream; nothing on the env streams waits for it
-            return ctx.all_gather_returns(returns[k & 1], async_op=True, n_total=n_total)
+            # per-episode return exchange on RCCL's stream; the env kernels of the next pass do not wait for it
+            out = ctx.all_gather_returns(returns[k & 1], async_op=True, n_total=n_total)
+            in_flight[k & 1] = out[1]
+            return out
         return None
 
     for w in range(args.warmup):
@@ -261,8 +273,6 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         pending.append(one_pass(k, True))
-        if len(pending) > 1 and pending[-2] is not None and pending[-2][1] is not None:
-            pending[-2][1].wait()           # the buffer of pass k-1 is reused by pass k+1
     for g in pending:
         if g is not None and g[1] is not None:
             g[1].wait()
