@@ -178,3 +178,28 @@ def test_instances_from_reference_dicts(golden_dir):
     assert a == A and all(np.array_equal(one[k], inst[k][2]) for k in ("depot", "task_xy", "req", "dur"))
     a, many = batch_from_dicts([dicts(i) for i in (0, 4, 9)])
     assert a == A and all(np.array_equal(many[k], inst[k][[0, 4, 9]]) for k in ("depot", "task_xy", "req", "dur"))
+
+
+def test_make_test_set_example(tmp_path, golden_dir):
+    """examples/make_test_set.py (TestSetGenerator.py:1-116): instance i = TaskEnv((A,A), (T,T), seed=i) in the reference's draw
+    order.  Depot and task coordinates equal the reference's shipped test set (same seeds, same first draws -- the shipped
+    pickles come from an older generator with random durations, so requirements / durations are compared with the current
+    draw order instead); the planner input files are written."""
+    import subprocess
+    import sys
+    from dcmrta_amd.instances import generate_instance_ranges, load_instances_npz
+    out = tmp_path / "testSet_20A_50T_CONDET"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "make_test_set.py"), "--out", str(out), "--num", "6"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got, A = load_instances_npz(str(out / "instances_20A50T.npz"))
+    want, A0 = load_instances_npz(os.path.join(golden_dir, "instances_20A50T.npz"))
+    assert A == A0 == 20
+    for k in ("depot", "task_xy"):
+        assert np.array_equal(got[k], want[k][:6]), k
+    for i in range(6):
+        _, ref = generate_instance_ranges((20, 20), (50, 50), i)            # draw order pinned against the reference in test_host
+        assert np.array_equal(got["req"][i], ref["req"]) and np.array_equal(got["dur"][i], ref["dur"]) and (got["dur"][i] == 5.0).all()
+        for name in ("vehicle_param", "task_param", "planner_param", "graph"):
+            assert (out / f"env_{i}" / f"{name}.yaml").exists()
