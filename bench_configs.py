@@ -304,8 +304,7 @@ def config4(B=8192, A=50, T=200, reps=3):
 
 
 def config5(B=1024, A=100, T=500):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_gpu_replay import synthetic_routes
+    from dcmrta_amd.instances import synthetic_routes
     inst = generate_batch(B, A, T, 0)
     out = {}
     for reactive in (False, True):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCMRTA_HIP_LIB") or os.path.join(_HERE, "libdcmrta_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FOLLOWER_COLS = 4
 MAX_MEMBERS = 5
 MAX_AGENTS = 128
@@ -36,6 +36,7 @@ _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SIGNATURES = {
     "dcm_last_error": (C.c_char_p, []),
     "dcm_abi_version": (C.c_int, []),
+    "dcm_build_id": (C.c_char_p, []),
     "dcm_create": (C.c_int, [C.POINTER(DcmParams), C.POINTER(_vp)]),
     "dcm_destroy": (C.c_int, [_vp]),
     "dcm_load_instances": (C.c_int, [_vp] * 6),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "dcm_set_route_log": (C.c_int, [_vp, _vp, _vp, _vp, _i32]),
     "dcm_load_routes": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dcm_execute_routes": (C.c_int, [_vp, _i32] + [_vp] * 11),
+    "dcm_set_visibility": (C.c_int, [_vp, _i32, _i32, _i32, _i32]),
 }
 
 _LIB = None
@@ -83,6 +85,11 @@ def load():
             raise DcmError("libdcmrta_hip.so ABI version mismatch")
         _LIB = lib
     return _LIB
+
+
+def build_id():
+    """sha256 prefix of the kernel sources + flags the loaded library was built from (dcm_build_id)."""
+    return load().dcm_build_id().decode()
 
 
 def check(rc):

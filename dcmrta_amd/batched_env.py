@@ -296,6 +296,12 @@ class BatchedTaskEnv:
             torch.cuda.current_stream(self.device).synchronize()
         return self
 
+    def set_visibility(self, initial=20, batch=20, period=10, cap=100):
+        """Dynamic-arrival schedule of the reactive replay: visible = clip(now // period * batch + initial, initial, cap)
+        (env/task_env.py:567; re-arm (next - 1) // batch * period, :221).  Defaults = the reference's hard-coded constants."""
+        check(self._lib.dcm_set_visibility(self._h, int(initial), int(batch), int(period), int(cap)))
+        return self
+
     def execute_routes(self, reactive=False):
         """execute_by_route + get_episode_reward for every env; returns a dict of device tensors."""
         B, A, T, dev = self.B, self.A, self.T, self.device

@@ -39,12 +39,28 @@ namespace {
 // libdcmrta_prof.so with -DDCM_PROFILE_PHASES; the product build compiles these macros to nothing).
 #ifdef DCM_PROFILE_PHASES
 __device__ unsigned long long g_phase_cycles[16];
+// k_step (lockstep kernel): per-env rows (no contended atomics: one wave owns its row).  Row e = 32 words: [0..7] phase cycles
+// summed over the launches, [8..15] their maxima over the launches, [16..27] the inner marks of apply_and_advance summed,
+// [28] launches in which the env was active  (tools/phase_profile.py lockstep)
+#define DCM_STEP_PROF_ENVS 65536
+__device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
+#define PHK_DECL unsigned long long phk_t = __builtin_readcyclecounter(); const unsigned long long phk_start = phk_t; \
+                 unsigned long long* const phk_row = g_step_rows + (size_t)(blockIdx.x % DCM_STEP_PROF_ENVS) * 32
+#define PHK_ADD(i, v) do { if (lane == 0) { phk_row[i] += (v); if (phk_row[8 + (i)] < (v)) phk_row[8 + (i)] = (v); } } while (0)
+#define PHK_MARK(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PHK_ADD(i, t_ - phk_t); phk_t = t_; } while (0)
+#define PHK_TOTAL(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PHK_ADD(i, t_ - phk_start); \
+                          if (lane == 0) phk_row[28] += 1; } while (0)
+#define PHK_INNER() do { if (lane == 0) for (int i_ = 0; i_ < 12; i_++) phk_row[16 + i_] += ph_acc[i_]; } while (0)
 #define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PH_MARK(i) do { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } while (0)
 #define PH_FLUSH(lane) do { if ((lane) == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); } while (0)
 #define PH_ARGS , unsigned long long& ph_t0, unsigned long long (&ph_acc)[12]
 #define PH_PASS , ph_t0, ph_acc
 #else
+#define PHK_DECL
+#define PHK_MARK(i)
+#define PHK_TOTAL(i)
+#define PHK_INNER()
 #define PH_DECL
 #define PH_MARK(i)
 #define PH_FLUSH(lane)
@@ -284,24 +300,8 @@ struct Sim {
             const bool full = todo == all;
             int n_infeas = full ? 0 : uni(st[0]);
             uint32_t dirty = 0;
-#ifdef DCM_INC_DEBUG   // dry run: would a full pass have changed a task outside the chunks about to be processed?
-            for (int t0 = 0; t0 < T_; t0 += WAVE) {
-                const int t = t0 + lane;
-                if (t < T_ && !((todo >> (t0 >> 6)) & 1u)) {
-                    const uint32_t i0 = tinfo()[t];
-                    const int req = i0 & 0xFF, n = (i0 >> 16) & 0xFF, st0 = (int)(int8_t)((i0 >> 8) & 0xFF);
-                    bool chg = false;
-                    double mx = __builtin_nan(""), mn = __builtin_nan("");
-                    for (int j = 0; j < M; j++) { mx = nanmax2(mx, marr()[j * PT_ + t]); mn = nanmin2(mn, marr()[j * PT_ + t]); }
-                    if (!(i0 & T_FEAS)) {
-                        const int status = req - n;
-                        if (status != st0) chg = true;
-                        if (status <= 0) { if (mx - mn <= mwt) chg = true; else if (mn <= mx - mwt) chg = true; }
-                        else if (now - mn >= mwt) chg = true;
-                    } else if (now >= tf()[t] && !(i0 & T_FIN)) chg = true;
-                    if (chg) printf("INC-DEBUG block %d d %llu task %d only %d info %08x now %.17g mn %.17g mx %.17g tf %.17g todo %x\n", (int)blockIdx.x, (unsigned long long)h.d, t, only, i0, now, mn, mx, tf()[t], todo);
-                }
-            }
+#ifdef DCM_INC_DEBUG   // developer self-check of the chunk skipping (tools/inc_selfcheck.py); never in the product build
+#include "../../tools/inc_selfcheck.inc"
 #endif
             for (uint32_t c = 0; c < nchunk; c++) {                            // uniform trip count and branch: ballots inside
                 if (!((todo >> c) & 1u)) continue;
@@ -1008,22 +1008,27 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    PHK_DECL;
     copy16_in(smem, rec, L.rec_bytes(), lane);
     S.set_ablog(ablog, e, BA, BT, lane);
     if (lane == 0) *S.dirty() = 0;
     WSYNC();
     Hdr h = load_hdr(smem);
+    PHK_MARK(0);                                   // record HBM -> LDS (issue + wait)
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
     if (was_active) {
         AMask gm;
         const uint64_t k1 = key1(h.seed, h.d);
         const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
+        PHK_MARK(1);                               // key + leader
         if (leader >= 0) {
             const int nf = nfol_in ? nfol_in[e] : -1;
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
                                 &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true, false, true);
+            PHK_MARK(2);                           // apply + updates + advance (+ terminal)
+            PHK_INNER();
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
             // the loaded instance, as k_rollout_random does between its episodes (the decision counter keeps running)
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) &&
@@ -1033,6 +1038,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 S.reset_state(h, lane);
                 if (lane == 0) *S.dirty() = Sim<CA, CT, RS>::DIRTY_ALL;
                 S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
+                PHK_MARK(3);                       // auto-reset: reset_state + first event
             }
         }
     }
@@ -1051,6 +1057,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             if (leader_out) leader_out[e] = leader;
             if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
         }
+        PHK_MARK(4);                               // next leader + observation stores (issue)
     }
     if (was_active) {
         WSYNC();
@@ -1075,7 +1082,9 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         }
         if (dm & Sim<CA, CT, RS>::DIRTY_IDS) put(L.mids(), L.tinfo());
         put(L.tinfo(), (dm & Sim<CA, CT, RS>::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
+        PHK_MARK(5);                               // write-back (issue)
     }
+    PHK_TOTAL(6);
 }
 
 // Config-2 hot path: whole episodes in one persistent launch, record resident in LDS.
@@ -1309,6 +1318,10 @@ extern "C" {
 
 const char* dcm_last_error(void) { return dcm::g_err; }
 int dcm_abi_version(void) { return DCM_ABI_VERSION; }
+#ifndef DCM_BUILD_ID
+#define DCM_BUILD_ID "unknown"
+#endif
+const char* dcm_build_id(void) { return DCM_BUILD_ID; }
 
 int dcm_create(const dcm_params* params, dcm_env** out) {
     if (!params || !out) return fail(DCM_ERR_INVALID, "dcm_create: null argument");
@@ -1610,6 +1623,12 @@ int dcm_distance(const double* ax, const double* ay, const double* bx, const dou
 int dcm_prof_read(unsigned long long* out16, int reset) {
     HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16));
     if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
+    return DCM_OK;
+}
+int dcm_prof_read_step(unsigned long long* out, int n_envs, int reset) {   // out[n_envs][32]
+    if (n_envs > DCM_STEP_PROF_ENVS) n_envs = DCM_STEP_PROF_ENVS;
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_rows), sizeof(unsigned long long) * 32 * (size_t)n_envs));
+    if (reset) { void* p = nullptr; HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_step_rows))); HIP_TRY(hipMemset(p, 0, sizeof(unsigned long long) * 32 * (size_t)DCM_STEP_PROF_ENVS)); }
     return DCM_OK;
 }
 #endif

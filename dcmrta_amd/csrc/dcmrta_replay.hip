@@ -53,6 +53,9 @@ struct RP {
     double mwt;     // 100, env/task_env.py:564
     double cutoff;  // 200, :565
     int reactive;
+    // dynamic-arrival schedule (dcm_set_visibility): visible = clip(now // period * batch + initial, initial, cap) :567 and
+    // the depot re-arm time (next - 1) // batch * period :221; the reference hard-codes 20 / 20 / 10 / 100
+    int vis_initial, vis_batch, vis_period, vis_cap;
 };
 
 // Python float floor division (now // 10, env/task_env.py:567)
@@ -185,7 +188,8 @@ struct Rep {
     }
 
     // env/task_env.py:207-243 including the reactive depot branch :213-224
-    __device__ void agent_update(double now, double mwt, int reactive, int visible, int lane, uint32_t& flags) const {
+    __device__ void agent_update(double now, double mwt, int reactive, int visible, int lane, uint32_t& flags, int vis_batch,
+                                 int vis_period) const {
         bool allf_vis = true;
         if (reactive) {                                                      // :214 all(feasible[:visible_length])
             const int lim = visible < T ? visible : T;
@@ -204,9 +208,9 @@ struct Rep {
                 if (len < 0) { terr = true; continue; }                      // :220 TypeError in the reference
                 // next preset action is read by the caller-provided pointer; stored in aw() scratch by the kernel
                 const int next_action = (int)aw()[a];                        // staged by stage_next()
-                int q = (next_action - 1) / 20;                              // :221 python floor division
-                if ((next_action - 1) % 20 != 0 && (next_action - 1) < 0) q--;
-                const double ndt = (double)(q * 10);
+                int q = (next_action - 1) / vis_batch;                       // :221 python floor division
+                if ((next_action - 1) % vis_batch != 0 && (next_action - 1) < 0) q--;
+                const double ndt = (double)(q * vis_period);
                 double v = arr()[a];                                         // :222 np.max([...])
                 v = ndt > v ? ndt : v;
                 v = now > v ? now : v;
@@ -280,8 +284,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     WSYNC();
     while (!finished_flag && now < P.cutoff) {                               // :565
         if (P.reactive) {                                                    // :566-567
-            double v = py_floordiv(now, 10.0) * 20.0 + 20.0;
-            v = v < 20.0 ? 20.0 : v; v = v > 100.0 ? 100.0 : v;
+            double v = py_floordiv(now, (double)P.vis_period) * (double)P.vis_batch + (double)P.vis_initial;
+            v = v < (double)P.vis_initial ? (double)P.vis_initial : v; v = v > (double)P.vis_cap ? (double)P.vis_cap : v;
             visible = (int)v;
         }
         // next_decision :283-289
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
         WSYNC();
         R.task_update(now, mwt, lane, -1, redo, n_infeas);                   // :570
         WSYNC();
-        R.agent_update(now, mwt, P.reactive, visible, lane, flags);          // :571
+        R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period);          // :571
         WSYNC();
         if (flags & R_TYPE_ERROR) break;
         if (!any) { if (++guard > 8) { flags |= DCM_FLAG_TRUNCATED; break; } } else guard = 0;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                 R.task_update(now, mwt, lane, redo ? -1 : (action > 0 ? action - 1 : -2), redo, n_infeas);   // :575/:582/:586
                 if (popped && lane == 0) R.aw()[a] = (double)upcoming;       // before agent_update: its reactive branch reads it
                 WSYNC();
-                R.agent_update(now, mwt, P.reactive, visible, lane, flags);  // :576/:583/:587
+                R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period);  // :576/:583/:587
                 WSYNC();
                 if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
             }
@@ -504,6 +508,14 @@ int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_le
     return DCM_OK;
 }
 
+int dcm_set_visibility(dcm_env* env, int32_t initial, int32_t batch, int32_t period, int32_t cap) {
+    CHECK_HANDLE(env);
+    if (initial < 0 || batch < 1 || period < 1 || cap < initial)
+        return fail(DCM_ERR_INVALID, "dcm_set_visibility: need initial >= 0, batch >= 1, period >= 1, cap >= initial");
+    env->vis[0] = initial; env->vis[1] = batch; env->vis[2] = period; env->vis[3] = cap;
+    return DCM_OK;
+}
+
 int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint32_t* flags_out, uint8_t* finished,
                        double* time_start, double* time_finish, double* task_wait, int32_t* n_members,
                        double* agent_wait, double* travel_dist, uint8_t* returned, void* stream) {
@@ -513,7 +525,7 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");
     const uint32_t lds = replay_lds_bytes(env->A, env->T, env->member_cap);
     (void)hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    RP P{100.0, 200.0, reactive ? 1 : 0};  // env/task_env.py:564-565
+    RP P{100.0, 200.0, reactive ? 1 : 0, env->vis[0], env->vis[1], env->vis[2], env->vis[3]};  // env/task_env.py:564-565,567
     hipLaunchKernelGGL(k_replay, GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T, env->member_cap, P, env->state,
                        env->routes, env->route_len, env->route_cap, env->summary, steps_out, flags_out, finished, time_start,
                        time_finish, task_wait, n_members, agent_wait, travel_dist, returned);

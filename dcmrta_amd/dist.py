@@ -13,6 +13,32 @@ import torch
 import torch.distributed as dist
 
 
+def _raw_bits(x):
+    """The values' bit patterns as int64 (reinterpreted, never converted): float64 / int64 as they are, 32-bit types widened."""
+    x = x.contiguous()
+    if x.dtype in (torch.float64, torch.int64):
+        return x.view(torch.int64)
+    if x.dtype in (torch.float32, torch.int32):
+        return x.view(torch.int32).to(torch.int64)
+    if x.dtype in (torch.float16, torch.bfloat16, torch.int16):
+        return x.view(torch.int16).to(torch.int64)
+    raise TypeError(f"verify_gather: unsupported dtype {x.dtype}")
+
+
+class _TrimAfterWait:
+    """Work handle of the uneven-shard gather: wait() = the collective's wait() + the trim of the padded blocks."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self):
+        self._work.wait()
+        if self._finish is not None:
+            self._finish()
+            self._finish = None
+        return True
+
+
 def shard_range(n_total, rank, world):
     """Contiguous block [lo, hi) of rank; the first n_total % world ranks hold one extra env."""
     base, rem = divmod(n_total, world)
@@ -83,13 +109,23 @@ class DistContext:
         n_loc = local_returns.numel()
         even = n_total is None or n_total == self.world * n_loc
         if not even:
+            # uneven blocks: every rank pads its block to ceil(n_total / world) for the collective; the gathered vector is
+            # trimmed back to the shard_range blocks -- after the (still asynchronous) collective has finished
             pad = -(-n_total // self.world)
             buf = torch.zeros((pad,), dtype=local_returns.dtype, device=local_returns.device)
             buf[:n_loc] = local_returns
-            full = self.all_gather_returns(buf)
             sizes = [shard_range(n_total, r, self.world) for r in range(self.world)]
-            out = torch.cat([full[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
-            return (out, None) if async_op else out
+
+            def trim(full, out=None):
+                parts = [full[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+                return torch.cat(parts, out=out) if out is not None else torch.cat(parts)
+            if async_op:
+                full, work = self.all_gather_returns(buf, async_op=True)
+                if work is None:
+                    return trim(full), None
+                out = torch.empty((n_total,), dtype=local_returns.dtype, device=local_returns.device)
+                return out, _TrimAfterWait(work, lambda: trim(full, out))
+            return trim(self.all_gather_returns(buf))
         if async_op and self.backend != "gloo":
             out = torch.empty((self.world * n_loc,), dtype=local_returns.dtype, device=local_returns.device)
             return out, dist.all_gather_into_tensor(out, local_returns, async_op=True)
@@ -108,20 +144,22 @@ class DistContext:
         the rank-major concatenation of every rank's local vector on every rank: each rank finds its own block at
         [first, first + B_local) bit for bit, and all ranks hold the same vector (min == max over ranks of a
         position-weighted checksum of the raw bits)."""
-        g = gathered.contiguous().view(torch.int64) if gathered.dtype == torch.float64 else gathered
-        l = local_returns.contiguous().view(torch.int64) if local_returns.dtype == torch.float64 else local_returns
+        g, l = _raw_bits(gathered), _raw_bits(local_returns)
         own_ok = bool(torch.equal(g[first:first + l.numel()].cpu(), l.cpu()))
         same = True
         if self._active():
-            w = torch.arange(1, g.numel() + 1, dtype=torch.int64, device=g.device)
-            h = float(((g.to(torch.int64) >> 12) * w).sum().to(torch.float64))
+            # two independent position-weighted sums of the raw bit patterns, in wrapping int64 arithmetic (no float cast, no
+            # dropped bits): vectors that differ anywhere disagree in at least one of them for all practical purposes
+            idx = torch.arange(1, g.numel() + 1, dtype=torch.int64, device=g.device)
+            h1 = (g * (2 * idx + 1)).sum()
+            h2 = ((g ^ (g >> 29)) * (idx * idx + 0x9E3779B1)).sum()
             dev = self._coll_device()
-            lo = torch.tensor([h, 1.0 if own_ok else 0.0], dtype=torch.float64, device=dev)
+            lo = torch.stack([h1, h2, torch.tensor(1 if own_ok else 0, dtype=torch.int64, device=g.device)]).to(dev)
             hi = lo.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            same = float(lo[0]) == float(hi[0])
-            all_own_ok = float(lo[1]) == 1.0
+            same = bool(torch.equal(lo[:2].cpu(), hi[:2].cpu()))
+            all_own_ok = int(lo[2]) == 1
         else:
             all_own_ok = own_ok
         if not own_ok:

@@ -104,3 +104,15 @@ def load_routes_json(path):
     """Preset routes {instance: [[0, k1, k2, ..., 0], ...]} in CTAS-D node numbering (baselines/CTAS-D.py:10-33)."""
     with open(path) as f:
         return {int(k): v for k, v in json.load(f).items()}
+
+
+def synthetic_routes(req, A, max_task=None):
+    """Preset routes for the route-replay benchmark (the reference ships routes for 20A/50T only):
+    every task t is visited by req[t] agents ((7t + j) mod A); each agent visits its tasks in ascending id, then the depot.
+    max_task: only the first max_task tasks are routed (the reference's visibility cap hides the rest)."""
+    T = len(req)
+    r = [[] for _ in range(A)]
+    for t in range(T if max_task is None else min(T, max_task)):
+        for j in range(int(req[t])):
+            r[(7 * t + j) % A].append(t + 1)
+    return [x + [0] for x in r]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCM_ABI_VERSION 2
+#define DCM_ABI_VERSION 3 /* v3: dcm_build_id, dcm_set_visibility, dcm_load_instances validates req on the device */
 
 typedef struct dcm_env dcm_env; /* opaque */
 
@@ -92,6 +92,9 @@ typedef struct {
 
 const char *dcm_last_error(void);
 int dcm_abi_version(void);
+/* 16 hex digits: sha256 over the kernel sources and compile flags this library was built from.  profiles/counters.json
+ * stores it with every rocprof counter set, so bench.py can tell when the counters describe another binary. */
+const char *dcm_build_id(void);
 
 /* TaskEnv.__init__ (env/task_env.py:9-34): allocate SoA state for B envs of (A,T). */
 int dcm_create(const dcm_params *params, dcm_env **out);
@@ -217,6 +220,15 @@ int dcm_distance(const double *ax, const double *ay, const double *bx, const dou
  * slots of replay mode, where a task may collect more agents than it requires. Arrays are copied. */
 int dcm_load_routes(dcm_env *env, const int32_t *routes, const int32_t *route_len, int32_t route_cap,
                     int32_t member_cap, void *stream);
+
+/* The dynamic-arrival schedule of execute_by_route's reactive mode.  The reference hard-codes it:
+ *   visible_length = int(np.clip(current_time // 10 * 20 + 20, 20, 100))     env/task_env.py:567
+ *   depot re-arm time (next_action - 1) // 20 * 10                           env/task_env.py:221
+ * i.e. 20 tasks at t = 0, 20 more every 10 time units, never more than 100 -- tasks 101.. of a larger instance never appear.
+ * Here the four constants are handle parameters (initial, batch, period, cap; defaults 20, 20, 10, 100 = the reference):
+ *   visible_length = int(clip(now // period * batch + initial, initial, cap)),  re-arm (next - 1) // batch * period.
+ * Needs initial >= 0, batch >= 1, period >= 1, cap >= initial.  Host-side setter; takes effect at the next dcm_execute_routes. */
+int dcm_set_visibility(dcm_env *env, int32_t initial, int32_t batch, int32_t period, int32_t cap);
 
 /* execute_by_route (env/task_env.py:562-593; max_waiting_time 100, cut-off 200) followed by get_episode_reward
  * (:420-425), whole episode in one launch.  reactive != 0 enables dynamic task visibility (:566-567,:578-584 and the

@@ -77,6 +77,8 @@ def lib():
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp, C.c_int, vp, C.c_int]
         L.orc_pre_set_route.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.orc_set_visibility.restype = C.c_int
+        L.orc_set_visibility.argtypes = [vp] + [C.c_int] * 4
         L.orc_execute_by_route.restype = C.c_int
         L.orc_execute_by_route.argtypes = [vp, C.c_int]
         L.orc_finish_episode.argtypes = [vp]
@@ -243,6 +245,12 @@ class OracleEnv:
     def pre_set_route(self, actions, agent):
         a = np.ascontiguousarray(actions, np.int32)
         lib().orc_pre_set_route(self._h, int(agent), _p(a), len(a))
+
+    def set_visibility(self, initial=20, batch=20, period=10, cap=100):
+        """The four constants of the dynamic-arrival schedule (env/task_env.py:567, :221); defaults = the reference."""
+        if lib().orc_set_visibility(self._h, int(initial), int(batch), int(period), int(cap)) != 0:
+            raise ValueError("need initial >= 0, batch >= 1, period >= 1, cap >= initial")
+        return self
 
     def execute_by_route(self, reactive=False):
         rc = lib().orc_execute_by_route(self._h, int(bool(reactive)))

@@ -46,6 +46,10 @@ struct orc_env {
     double now;      /* current_time :28 */
     int finished;    /* :31 */
     int reactive, visible_length; /* :33-34 */
+    /* dynamic-arrival schedule of execute_by_route: the reference hard-codes 20 / 20 / 10 / 100 (:567, :221); kept as
+     * parameters so that a generalised schedule (e.g. all 500 tasks of a 100A/500T instance eventually visible) can be
+     * replayed -- a literal substitution of those four constants, pinned by tests/golden/make_golden_schedule.py */
+    int vis_initial, vis_batch, vis_period, vis_cap;
     int truncated;   /* guard flag, not in the reference (SURVEY §5 hazard) */
     int type_error;  /* the reference would have raised TypeError (:220) */
     double depot[2];
@@ -116,6 +120,7 @@ static double py_floordiv(double vx, double wx) {
 orc_env *orc_create(int A, int T) {
     orc_env *e = (orc_env *)calloc(1, sizeof(orc_env));
     e->A = A; e->T = T; e->mwt = 10.0; e->max_time = 100.0;
+    e->vis_initial = 20; e->vis_batch = 20; e->vis_period = 10; e->vis_cap = 100;   /* env/task_env.py:567, :221 */
 #define DA(p, n) e->p = calloc((size_t)(n), sizeof(*e->p))
     DA(tx, T); DA(ty, T); DA(tdur, T); DA(ts, T); DA(tf, T); DA(task_wait, T);
     DA(req, T); DA(status, T); DA(feasible, T); DA(tfin, T); DA(members, T); DA(abandoned, T);
@@ -256,8 +261,8 @@ void orc_agent_update(orc_env *e) {
                             if (e->preset_none[a]) { e->type_error = 1; return; } /* :220 raises TypeError */
                             int next_action = e->preset[a].v[e->preset_head[a]];  /* :220 */
                             /* :221 python int floor division */
-                            int q = (next_action - 1) / 20; if ((next_action - 1) % 20 != 0 && (next_action - 1) < 0) q--;
-                            double ndt = (double)(q * 10);
+                            int q = (next_action - 1) / e->vis_batch; if ((next_action - 1) % e->vis_batch != 0 && (next_action - 1) < 0) q--;
+                            double ndt = (double)(q * e->vis_period);
                             double v = get_arrival_time(e, a, -1);          /* :222 np.max([..]) */
                             if (ndt > v) v = ndt;
                             if (e->now > v) v = e->now;
@@ -604,6 +609,13 @@ void orc_pre_set_route(orc_env *e, int agent, const int32_t *actions, int n) {
     for (int i = 0; i < n; i++) iv_push(&e->preset[agent], actions[i]);
 }
 
+/* the four constants of env/task_env.py:567 / :221 (defaults 20, 20, 10, 100 = the reference) */
+int orc_set_visibility(orc_env *e, int initial, int batch, int period, int cap) {
+    if (initial < 0 || batch < 1 || period < 1 || cap < initial) return -1;
+    e->vis_initial = initial; e->vis_batch = batch; e->vis_period = period; e->vis_cap = cap;
+    return 0;
+}
+
 /* env/task_env.py:562-593 */
 int orc_execute_by_route(orc_env *e, int reactive) {
     int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * e->A);
@@ -613,9 +625,9 @@ int orc_execute_by_route(orc_env *e, int reactive) {
     long steps = 0, step_cap = 64L * (e->A + e->T) + 4096; /* guard shared with the HIP kernel (not in the reference) */
     while (!e->finished && e->now < 200.0) {                                /* :565 */
         if (e->reactive) {                                                  /* :566-567 */
-            double v = py_floordiv(e->now, 10.0) * 20.0 + 20.0;
-            if (v < 20.0) v = 20.0;
-            if (v > 100.0) v = 100.0;
+            double v = py_floordiv(e->now, (double)e->vis_period) * (double)e->vis_batch + (double)e->vis_initial;
+            if (v < (double)e->vis_initial) v = (double)e->vis_initial;   /* np.clip(.., 20, 100) */
+            if (v > (double)e->vis_cap) v = (double)e->vis_cap;
             e->visible_length = (int)v;
         }
         double t;

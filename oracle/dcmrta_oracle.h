@@ -89,6 +89,9 @@ int orc_get_abandoned(orc_env *e, int task, int32_t *out, int cap); /* task['aba
 void orc_pre_set_route(orc_env *e, int agent, const int32_t *actions, int n);
 /* returns 0 ok, -2 if the reference would raise TypeError at :220 (pre_set_route None) */
 int orc_execute_by_route(orc_env *e, int reactive);
+/* dynamic-arrival schedule: visible_length = int(clip(now // period * batch + initial, initial, cap)) (:567) and the depot
+ * re-arm time (next - 1) // batch * period (:221).  The reference hard-codes 20 / 20 / 10 / 100 (the defaults here). */
+int orc_set_visibility(orc_env *e, int initial, int batch, int period, int cap);
 void orc_finish_episode(orc_env *e); /* get_episode_reward: calculate_waiting_time + check_finished */
 
 /* numpy add.reduce restated (pairwise summation); exposed for a unit test against numpy */

@@ -55,14 +55,7 @@ def test_ctasd_routes_known_answer(gpu_device, golden_dir, reactive, fixture):
         assert round(sm[:, 6].mean(), 3) == 42.027 and round(sm[:, 7].mean(), 3) == 2.248
 
 
-def synthetic_routes(req, A, max_task=None):
-    """Every task t is visited by req[t] agents ((7t + j) mod A); each agent visits its tasks in ascending id, then the depot."""
-    T = len(req)
-    r = [[] for _ in range(A)]
-    for t in range(T if max_task is None else min(T, max_task)):
-        for j in range(int(req[t])):
-            r[(7 * t + j) % A].append(t + 1)
-    return [x + [0] for x in r]
+from dcmrta_amd.instances import synthetic_routes  # noqa: E402
 
 
 @pytest.mark.parametrize("A,T,reactive", [(100, 500, False), (100, 500, True), (100, 100, True), (50, 200, True), (13, 37, False)])

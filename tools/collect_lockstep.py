@@ -11,7 +11,7 @@ import os
 import sys
 
 name, B, A, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-base = "gpurun_out/prof_lockstep/"
+base = f"gpurun_out/prof_lockstep_B{B}_{A}A{T}T/"
 dst = f"profiles/{name}"
 os.makedirs(dst, exist_ok=True)
 cmd = open(base + "command.txt").read().strip()
@@ -27,9 +27,12 @@ with open(out, "w") as f:
                 avg_ns = float(next(csv.reader([l]))[3])
     tot = {}
     f.write("counter,dispatches,avg_per_dispatch\n")
-    for d in ("pmc_fetch", "pmc_write", "pmc_sqa"):
+    for d in ("pmc_fetch", "pmc_write", "pmc_sqa", "pmc_sqb"):
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(glob.glob(base + f"{d}/**/*counter_collection.csv", recursive=True)[0])):
+        hits = glob.glob(base + f"{d}/**/*counter_collection.csv", recursive=True)
+        if not hits:
+            continue
+        for r in csv.DictReader(open(hits[0])):
             if "k_step" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
