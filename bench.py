@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/sec of the batched coalition-formation + routing rollout (BASELINE.json metric).
 
-One bench "step" = one pass of the hot path over one batch: every env of the batch plays its consecutive complete
-episodes (3 per env, auto-reset to the same instance, the decision counter keeps running) under
-the uniform-random valid policy inside the persistent HIP kernel (dcm_rollout_random), with the observation tensors + mask
-built and stored at every decision.  value = decisions taken by all envs on all ranks / wall time, inputs (instances,
-seeds, state) resident in HBM before the timed region starts.
+One bench "step" = one pass of the hot path over one batch.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4] [--streams S]
+--config 2 (default) = BASELINE.json configs[1]: 4096 parallel envs per GPU, 20 agents / 50 tasks; every env plays 3
+    consecutive complete episodes (auto-reset to the same instance, the decision counter keeps
+    running) under the uniform-random valid policy inside the persistent HIP kernel (dcm_rollout_random), with the
+    observation tensors + mask built and stored at every decision.  N > 1 shards more envs (weak scaling).
+--config 4 = BASELINE.json configs[3]: 65 536 envs of 50A/200T in total, sharded over the N ranks by contiguous blocks
+    (strong scaling), one episode per env per pass.
+--config 5 = BASELINE.json configs[4]: route replay (execute_by_route) of 100A/500T instances with dynamic task arrivals,
+    8192 envs in total sharded over the N ranks (strong scaling); a step of this config = one agent_step call of the
+    replay.  Preset routes are synthetic (the reference ships routes for 20A/50T only).  --visibility initial,batch,period,cap
+    selects another dynamic-arrival schedule than the reference's hard-coded 20,20,10,100 (under which tasks 101..500 never
+    appear): reported as a separate workload, never as the config-5 number.
+
+value = steps taken by all envs on all ranks / wall time, inputs (instances, seeds, routes, state) resident in HBM before
+the timed region starts.  There is no data-path collective; one RCCL all-gather of the per-env EPISODE returns per pass (every
+episode of the pass: returns[B_local, episodes]) -- the analogue of ray.get in driver.py:129-130 -- issued asynchronously so
+that it overlaps with the next pass.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--streams S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-
---config 2 (default) = BASELINE.json configs[1]: 4096 parallel envs per GPU, 20 agents / 50 tasks, random policy, HIP env
-only; N > 1 shards more envs (weak scaling).  --config 4 = BASELINE.json configs[3]: 65 536 envs of 50A/200T in total,
-sharded over the N ranks by contiguous blocks (strong scaling), one episode per env per pass.  Either way there is no
-data-path collective; one RCCL all-gather of the per-env episode returns per pass (the analogue of ray.get in
-driver.py:129-130), issued asynchronously so that it overlaps with the next pass.
 
 --streams S: the rank's env block is cut into S contiguous sub-batches, each with its own handle and HIP stream.  A pass
 is then S launches; a launch lasts as long as its slowest env, and with several independent streams one sub-batch's tail
@@ -29,7 +36,8 @@ import time
 
 # The sub-batches of a pass run on separate HIP streams; the runtime maps streams onto 4 hardware queues by default and
 # kernels that share a queue serialise.  Must be set before the HIP runtime initialises (measured on MI355X, 4096 envs:
-# 4 streams on 4 queues 5.3e8 steps/s, on 8 queues 9.5e8).
+# 4 streams on 4 queues 5.3e8 steps/s, on 8 queues 9.5e8).  (tools/profile.sh exports it too: under rocprofv3 the profiler
+# initialises HIP before this line runs.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -38,17 +46,20 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from dcmrta_amd import _lib  # noqa: E402
 from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
 from dcmrta_amd.choice import env_seeds  # noqa: E402
 from dcmrta_amd.dist import DistContext, shard_range  # noqa: E402
-from dcmrta_amd.instances import generate_batch  # noqa: E402
-from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, N_SIMD, PEAK_CLOCK_HZ, algorithmic_bytes_per_step,  # noqa: E402
-                                 load_counters)
+from dcmrta_amd.instances import generate_batch, synthetic_route_arrays  # noqa: E402
+from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step, issue_roofline, load_counters,  # noqa: E402
+                                 staleness)
 
+REFERENCE_VISIBILITY = (20, 20, 10, 100)      # env/task_env.py:567, :221
 CONFIGS = {
-    # name: (envs, agents, tasks, episodes per pass, scaling, label)
-    "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]"),
-    "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]"),
+    # name: envs, agents, tasks, episodes per pass, scaling, label, kernel
+    "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]", kernel="k_rollout_random"),
+    "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]", kernel="k_rollout_random"),
+    "5": dict(envs=8192, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
 }
 AUTO_STREAM_CANDIDATES = (4, 2, 1)   # --streams 0: pick the fastest of these in an untimed calibration before the warm-up
 
@@ -109,6 +120,35 @@ def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
                 single_thread_rate=rate1)
 
 
+def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seconds=12.0):
+    """Config 5: the oracle's execute_by_route (reactive) on the host cores, one env per thread (the ctypes call releases the
+    GIL), on a bounded sample of the same instances and routes."""
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    oracle.build()
+    cores = usable_cores()
+
+    def one(b):
+        o = oracle.OracleEnv(A, inst["req"].shape[1]).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        o.set_visibility(*visibility)
+        for a in range(A):
+            if route_len[b, a] >= 0:
+                o.pre_set_route(routes[b, a, :route_len[b, a]], a)
+        return int(o.execute_by_route(True)["route_len"].sum())          # agent_step calls of the episode
+    t0 = time.perf_counter()
+    n0 = one(0)
+    dt0 = time.perf_counter() - t0
+    n_envs = int(max(cores, min(len(route_len), round(target_core_seconds / max(dt0, 1e-6)))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        n = sum(ex.map(one, range(n_envs)))
+    rate = n / (time.perf_counter() - t0)
+    return dict(value=rate, unit="steps/s", cores=cores, kind="port",
+                sample=f"{n_envs} envs ({n} agent steps) of the same instances / routes, oracle C port of execute_by_route with "
+                       f"dynamic visibility, {cores} threads, one env per thread",
+                single_thread_rate=n0 / dt0)
+
+
 def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
     """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
     decision: the HBM roofline of this path is quoted on it, at a batch that fills the machine, HIP events around
@@ -128,7 +168,9 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
     out = {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
            "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
            "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9), "algorithmic_bytes_per_launch": B * Wb,
-           "traffic": c.get("hbm_bytes_per_launch") if c else None, "counters_source": c.get("source") if c else None}
+           "traffic": c.get("hbm_bytes_per_launch") if c else None, "counters_source": c.get("source") if c else None,
+           "rocprof_avg_launch_us": c.get("avg_launch_us") if c else None,
+           "stale": staleness(c, _lib.build_id()) if c else None}
     env.close()
     return out
 
@@ -136,14 +178,29 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
 class SubBatch:
     """One contiguous block of the rank's envs: its own handle and (for more than one sub-batch) its own HIP stream."""
 
-    def __init__(self, first, B, A, T, dev, stream):
-        self.first, self.B, self.stream = first, B, stream
+    def __init__(self, cfg, first, B, dev, stream, visibility):
+        A, T = cfg["agents"], cfg["tasks"]
+        self.first, self.B, self.stream, self.replay = first, B, stream, cfg["kernel"] == "k_replay"
         self.inst = generate_batch(B, A, T, base_seed=0, first=first)
         self.seeds = env_seeds(0, first, B)
         self.env = BatchedTaskEnv(B, A, T, device=str(dev))
         self.env.load_instances(**self.inst)
-        self.env.reset(self.seeds, observe=False)
+        if self.replay:
+            # routes only over the tasks that can ever become visible under the schedule (the reference's cap hides the rest)
+            self.routes, self.route_len = synthetic_route_arrays(self.inst["req"], A, max_task=min(T, visibility[3]))
+            self.env.set_visibility(*visibility)
+            self.env.load_route_arrays(self.routes, self.route_len, member_cap=8)
+        else:
+            self.ring = self.env.enable_return_log(cfg["episodes"])          # every episode's return of a pass
+            self.env.reset(self.seeds, observe=False)
         self.counts, self.ev, self.warm = [], [], []
+
+    def run(self, episodes, write_obs):
+        """One pass of this sub-batch; returns (steps int64[B], returns f64[B, episodes])."""
+        if self.replay:
+            out = self.env.execute_routes(True, fields=())
+            return out["steps"], out["summary"][:, :1]
+        return self.env.rollout_random(episodes=episodes, write_obs=write_obs), self.ring
 
 
 def main():
@@ -152,12 +209,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="2")
-    ap.add_argument("--envs", type=int, default=None, help="config 2: envs per GPU; config 4: envs in total")
+    ap.add_argument("--envs", type=int, default=None, help="config 2: envs per GPU; configs 4 / 5: envs in total")
     ap.add_argument("--agents", type=int, default=None)
     ap.add_argument("--tasks", type=int, default=None)
-    ap.add_argument("--episodes", type=int, default=None, help="consecutive episodes per env per pass")
+    ap.add_argument("--episodes", type=int, default=None, help="consecutive episodes per env per pass (configs 2 / 4)")
     ap.add_argument("--streams", type=int, default=0,
                     help="sub-batches (HIP streams) per GPU; 0 = calibrate 4 / 2 / 1 before the warm-up and keep the fastest")
+    ap.add_argument("--visibility", default=None,
+                    help="config 5: initial,batch,period,cap of the dynamic-arrival schedule (default: the reference's 20,20,10,100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
@@ -167,6 +226,10 @@ def main():
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     A, T, EP = cfg["agents"], cfg["tasks"], cfg["episodes"]
+    replay = cfg["kernel"] == "k_replay"
+    visibility = tuple(int(x) for x in args.visibility.split(",")) if args.visibility else REFERENCE_VISIBILITY
+    if replay:
+        EP = 1
 
     ctx = DistContext.from_env(expected_world=args.gpus)
     dev = ctx.device
@@ -187,7 +250,7 @@ def main():
         out = []
         for k in range(S):
             lo, hi = shard_range(B, k, S)
-            out.append(SubBatch(first + lo, hi - lo, A, T, dev, main_stream if S == 1 else side_streams[k]))
+            out.append(SubBatch(cfg, first + lo, hi - lo, dev, main_stream if S == 1 else side_streams[k], visibility))
         torch.cuda.synchronize(dev)
         return out
 
@@ -200,7 +263,7 @@ def main():
             for _ in range(passes if timed else 1):
                 for sb in subs_c:
                     with torch.cuda.stream(sb.stream):
-                        sb.env.rollout_random(episodes=EP, write_obs=not args.no_obs)
+                        sb.run(EP, not args.no_obs)
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - t0) / passes
         for sb in subs_c:
@@ -210,13 +273,15 @@ def main():
     calibration = None
     if args.streams > 0:
         S = max(1, min(args.streams, B))
+    elif replay:
+        S = 1       # two resident waves per CU: a replay launch is many rounds of workgroups, there is no launch tail to hide
     else:
         # how many streams pay off depends on how the runtime maps them onto hardware queues (see GPU_MAX_HW_QUEUES above):
         # measure instead of assuming
         calibration = {c: calibrate(c) for c in AUTO_STREAM_CANDIDATES if c <= B}
         S = min(calibration, key=calibration.get)
     subs = make_subs(S)
-    returns = [torch.empty((B,), dtype=torch.float64, device=dev) for _ in range(2)]   # double-buffered per-pass returns
+    returns = [torch.empty((B, EP), dtype=torch.float64, device=dev) for _ in range(2)]   # double-buffered per-pass returns
     in_flight = [None, None]          # the gather still reading returns[i], if any
 
     def one_pass(k, timed):
@@ -233,7 +298,7 @@ def main():
             with torch.cuda.stream(sb.stream):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                steps = sb.env.rollout_random(episodes=EP, write_obs=not args.no_obs)
+                steps, rets = sb.run(EP, not args.no_obs)
                 e1.record()
                 if timed:
                     sb.counts.append(steps)
@@ -244,7 +309,7 @@ def main():
                     lo = sb.first - first
                     if free is not None:
                         sb.stream.wait_event(free)
-                    returns[k & 1][lo:lo + sb.B].copy_(sb.env.summary()[:, 0])
+                    returns[k & 1][lo:lo + sb.B].copy_(rets)         # the return of EVERY episode of the pass
                     d = torch.cuda.Event()
                     d.record()
                     done.append(d)
@@ -252,7 +317,7 @@ def main():
             for d in done:
                 main_stream.wait_event(d)
             # per-episode return exchange on RCCL's stream; the env kernels of the next pass do not wait for it
-            out = ctx.all_gather_returns(returns[k & 1], async_op=True, n_total=n_total)
+            out = ctx.all_gather_returns(returns[k & 1].view(-1), async_op=True, n_total=n_total, width=EP)
             in_flight[k & 1] = out[1]
             return out
         return None
@@ -264,8 +329,8 @@ def main():
     torch.cuda.synchronize(dev)
     if ctx.active:
         # the gathered vector is the rank-major concatenation of the per-rank return vectors on EVERY rank
-        local = torch.cat([sb.env.summary()[:, 0] for sb in subs])
-        ctx.verify_gather(ctx.all_gather_returns(local, n_total=n_total), local, first)
+        local = (torch.cat([sb.env.summary()[:, :1] if sb.replay else sb.ring for sb in subs]).contiguous().view(-1))
+        ctx.verify_gather(ctx.all_gather_returns(local, n_total=n_total, width=EP), local, first * EP)
     K = args.steps
     pending = []
     ctx.barrier()
@@ -285,69 +350,77 @@ def main():
     launch_ms = [a.elapsed_time(b) for sb in subs for a, b in sb.ev]
     warm_steps = int(sum(int(torch.stack(sb.warm).sum().item()) for sb in subs if sb.warm))
 
-    for sb in subs:
-        flags = sb.env.status()["flags"].cpu().numpy()
-        assert (flags & 0x38).sum() == 0, "env error flags set"
+    if not replay:
+        for sb in subs:
+            flags = sb.env.status()["flags"].cpu().numpy()
+            assert (flags & 0x138).sum() == 0, "env error flags set"
     if ctx.rank != 0:
         ctx.shutdown()
         return
 
     step_s = elapsed / K
     dec_per_step = local_steps / K
+    unit = "agent_step" if replay else "decision"
     Wb = algorithmic_bytes_per_step(A, T)
-    c = load_counters(f"k_rollout_random:{A}A{T}T")           # per-decision PMC averages measured by tools/profile.sh
-    roof = {"kernel": "k_rollout_random", "avg_launch_ms": float(np.mean(launch_ms)), "launches_per_step": S,
-            "decisions_per_step": dec_per_step}
+    vis_tag = "" if (not replay or visibility == REFERENCE_VISIBILITY) else ":vis" + "-".join(str(v) for v in visibility)
+    c = load_counters(f"{cfg['kernel']}:{A}A{T}T{vis_tag}")      # per-step PMC averages measured by tools/profile.sh
+    build = _lib.build_id()
+    roof = {"kernel": cfg["kernel"], "avg_launch_ms": float(np.mean(launch_ms)), "launches_per_step": S,
+            f"{unit}s_per_step": dec_per_step}
     if c:
-        # Issue-bound roofline: the persistent kernel keeps the record in LDS, so HBM is not what limits it (hbm.frac
-        # below); the binding resource is VALU issue.  SQ_ACTIVE_INST_VALU counts, per wave, the quad-cycles (4 clocks:
-        # one wave64 instruction on a 16-lane SIMD) the VALU spends executing that wave's instructions
-        # (profiles/r02_calib: == SQ_INSTS_VALU for fp64 FMA streams).  achieved = VALU-busy SIMD-cycles per second of
-        # this run, peak = 1024 SIMDs x 2.4 GHz.
-        valu_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU_per_decision"] * dec_per_step
-        achieved = valu_cycles / step_s / 1e9
-        peak = N_SIMD * PEAK_CLOCK_HZ / 1e9
+        # Issue-bound roofline: the persistent kernels keep the env in LDS, so HBM is not what limits them (roofline.hbm
+        # below); the binding resource is instruction issue.  Instruction counts per step come from the committed rocprofv3
+        # PMC profile of this same command, priced per instruction class with the clocks of profiles/r03_calib; decisions and
+        # times are live from this run (HIP events on the launch streams).
+        roof.update(issue_roofline(c, dec_per_step, step_s, unit="decision"))
         traffic = c.get("hbm_bytes_per_decision")
         traffic = traffic * dec_per_step if traffic is not None and not args.no_obs else None
-        roof.update({"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s (VALU busy)",
-                     "frac": achieved / peak,
-                     "lane_util": c["SQ_THREAD_CYCLES_VALU_per_decision"] / (64.0 * c["SQ_ACTIVE_INST_VALU_per_decision"]),
-                     "valu_insts_per_decision": c.get("SQ_INSTS_VALU_per_decision"),
-                     "salu_insts_per_decision": c.get("SQ_INSTS_SALU_per_decision"),
-                     "traffic": traffic,
+        roof.update({"traffic": traffic,
                      "hbm": {"achieved": (traffic / step_s / 1e9) if traffic else None, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                              "unit": "GB/s", "frac": (traffic / step_s / HBM_PEAK_BYTES_PER_S) if traffic else None,
                              "note": "measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE) per pass / pass time"},
-                     "counters_source": c.get("source")})
+                     "counters_source": c.get("source"), "counters_build_id": c.get("build_id"), "build_id": build,
+                     # the counters describe the binary they were profiled on: a kernel edit without a re-profile shows here
+                     "stale": staleness(c, build)})
     else:
-        roof.update({"bound": "valu_issue", "achieved": None, "peak": N_SIMD * PEAK_CLOCK_HZ / 1e9,
-                     "unit": "G SIMD-cycles/s (VALU busy)", "frac": None, "traffic": None,
-                     "note": f"no PMC profile committed for {A}A/{T}T (profiles/counters.json)"})
+        roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G SIMD-clocks/s (VALU pipe busy)",
+                     "frac": None, "traffic": None, "build_id": build,
+                     "note": f"no PMC profile committed for {cfg['kernel']}:{A}A{T}T{vis_tag} (profiles/counters.json)"})
     # SURVEY.md §8(d) prices a decision with W = 2S + O + 4 algorithmic bytes whatever the kernel really moves; for the
-    # LDS-resident kernel that figure is NOT a utilisation (it exceeds the HBM peak) and is reported only for the record
+    # LDS-resident kernels that figure is NOT a utilisation (it exceeds the HBM peak) and is reported only for the record
     roof["w_scored"] = {"algorithmic_bytes_per_step": Wb, "equiv_GBps": dec_per_step * Wb / step_s / 1e9,
                         "note": "SURVEY §8(d) pricing; the record never leaves LDS, see roofline.hbm for real traffic"}
+    what = (f"route replay with dynamic task arrivals (visibility schedule initial,batch,period,cap = {visibility}"
+            + (", the reference's constants" if visibility == REFERENCE_VISIBILITY else ", GENERALISED: not the reference's constants")
+            + "), synthetic preset routes") if replay else "random-policy rollout"
     out = {
         "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": cfg["scaling"],
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"{B} envs/GPU x {A}A/{T}T random-policy rollout, HIP env only ({cfg['label']})"
+        "config": {"workload": (f"{B} envs/GPU x {A}A/{T}T {what}, HIP env only ({cfg['label']})"
                                 if cfg["scaling"] == "weak" else
-                                f"{n_total} envs x {A}A/{T}T random-policy rollout sharded over {ctx.world} GPU(s), HIP env only "
+                                f"{n_total} envs x {A}A/{T}T {what} sharded over {ctx.world} GPU(s), HIP env only "
                                 f"({cfg['label']})"),
+                   "step_definition": ("one agent_step call of execute_by_route (env/task_env.py:572-587)" if replay else
+                                       "one leader decision (TaskEnv.step + updates + next observation)"),
                    "envs_per_gpu": B, "envs_total": n_total, "agents": A, "tasks": T, "episodes_per_step": EP,
                    "decisions_per_step_per_gpu": dec_per_step, "decisions_in_warmup_per_gpu": warm_steps, "streams_per_gpu": S,
                    "stream_calibration_ms_per_pass": ({str(k): v * 1e3 for k, v in calibration.items()} if calibration else None),
+                   "visibility": list(visibility) if replay else None,
                    "sharding": f"env batch x{ctx.world}, no data-path collective"
-                               + (", one async all-gather of the episode returns per pass" if ctx.active else ""),
+                               + (f", one async all-gather of the {EP} episode return(s) of every env per pass" if ctx.active else ""),
                    "dist_backend": ctx.backend or None},
         "roofline": roof,
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
         sb = subs[0]
         inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
-        out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
-    if ctx.world == 1 and not args.no_lockstep_probe:
+        if replay:
+            out["cpu_baseline"] = cpu_baseline_replay(inst, np.concatenate([x.routes for x in subs]),
+                                                      np.concatenate([x.route_len for x in subs]), A, visibility)
+        else:
+            out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
+    if ctx.world == 1 and not args.no_lockstep_probe and not replay:
         for sb in subs:
             sb.env.close()
         out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)

@@ -18,6 +18,7 @@ MAX_AGENTS = 128
 MAX_TASKS = 1023
 
 FLAG_DONE, FLAG_FINISHED, FLAG_TRUNCATED, FLAG_BAD_ACTION, FLAG_OVERFLOW, FLAG_BAD_LEADER, FLAG_TYPE_ERROR = 1, 2, 4, 8, 16, 32, 64
+FLAG_BAD_INSTANCE = 256  # a requirement outside 1..MAX_MEMBERS reached dcm_load_instances: the env never starts
 FLAG_WAIT_ORDER = 128   # informational: a per-(agent, task) abandonment counter saturated (RL mode) / replay log overflow
 
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dcm_load_routes": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dcm_execute_routes": (C.c_int, [_vp, _i32] + [_vp] * 11),
     "dcm_set_visibility": (C.c_int, [_vp, _i32, _i32, _i32, _i32]),
+    "dcm_set_return_log": (C.c_int, [_vp, _vp, _i32]),
 }
 
 _LIB = None

@@ -262,6 +262,15 @@ class BatchedTaskEnv:
             check(self._lib.dcm_get_abandoned(self._h, _ptr(out), self._stream()))
         return out
 
+    def enable_return_log(self, cap):
+        """Keep every episode's return: f64[B, cap] ring, the k-th episode an env finishes since reset() lands in column
+        k mod cap (dcm_set_return_log).  summary() keeps only the last episode; with cap = episodes per rollout_random call
+        all of a call's episode returns are here afterwards.  cap = 0 disables."""
+        self._retlog = torch.full((self.B, int(cap)), float("nan"), dtype=torch.float64, device=self.device) if cap else None
+        check(self._lib.dcm_set_return_log(self._h, _ptr(self._retlog), int(cap)))
+        self.graph_epoch += 1
+        return self._retlog
+
     # ------------------------------------------------------------------ route history (agent['route'], agent['arrival_time'])
     def enable_route_log(self, cap=64):
         """Record every agent_step of the lockstep API (reset / step): route_task[B,A,cap] (-1 = depot), route_arrival, route_len."""
@@ -290,9 +299,16 @@ class BatchedTaskEnv:
                 if r is not None:
                     ln[b, a] = len(r)
                     arr[b, a, :len(r)] = r
-        d_arr, d_ln = self._dev(arr, torch.int32), self._dev(ln, torch.int32)
+        return self.load_route_arrays(arr, ln, member_cap)
+
+    def load_route_arrays(self, routes, route_len, member_cap=8):
+        """routes int32[B,A,cap] (actions, 0-padded), route_len int32[B,A] (-1 = pre_set_route stays None): dcm_load_routes."""
+        routes, route_len = np.ascontiguousarray(routes, np.int32), np.ascontiguousarray(route_len, np.int32)
+        if routes.ndim != 3 or routes.shape[:2] != (self.B, self.A) or route_len.shape != (self.B, self.A):
+            raise DcmError(f"routes must be int32[{self.B},{self.A},cap] and route_len int32[{self.B},{self.A}]")
+        d_arr, d_ln = self._dev(routes, torch.int32), self._dev(route_len, torch.int32)
         with torch.cuda.device(self.device):
-            check(self._lib.dcm_load_routes(self._h, _ptr(d_arr), _ptr(d_ln), cap, int(member_cap), self._stream()))
+            check(self._lib.dcm_load_routes(self._h, _ptr(d_arr), _ptr(d_ln), int(routes.shape[2]), int(member_cap), self._stream()))
             torch.cuda.current_stream(self.device).synchronize()
         return self
 
@@ -302,20 +318,19 @@ class BatchedTaskEnv:
         check(self._lib.dcm_set_visibility(self._h, int(initial), int(batch), int(period), int(cap)))
         return self
 
-    def execute_routes(self, reactive=False):
-        """execute_by_route + get_episode_reward for every env; returns a dict of device tensors."""
+    def execute_routes(self, reactive=False, fields=None):
+        """execute_by_route + get_episode_reward for every env; returns a dict of device tensors.
+        fields: which of the optional per-task / per-agent arrays to produce (default: all; () = steps, flags, summary only)."""
         B, A, T, dev = self.B, self.A, self.T, self.device
-        o = dict(steps=torch.empty((B,), dtype=torch.int64, device=dev), flags=torch.empty((B,), dtype=torch.int32, device=dev),
-                 finished=torch.empty((B, T), dtype=torch.uint8, device=dev),
-                 time_start=torch.empty((B, T), dtype=torch.float64, device=dev),
-                 time_finish=torch.empty((B, T), dtype=torch.float64, device=dev),
-                 task_wait=torch.empty((B, T), dtype=torch.float64, device=dev),
-                 n_members=torch.empty((B, T), dtype=torch.int32, device=dev),
-                 agent_wait=torch.empty((B, A), dtype=torch.float64, device=dev),
-                 travel_dist=torch.empty((B, A), dtype=torch.float64, device=dev),
-                 returned=torch.empty((B, A), dtype=torch.uint8, device=dev))
+        spec = dict(finished=((B, T), torch.uint8), time_start=((B, T), torch.float64), time_finish=((B, T), torch.float64),
+                    task_wait=((B, T), torch.float64), n_members=((B, T), torch.int32), agent_wait=((B, A), torch.float64),
+                    travel_dist=((B, A), torch.float64), returned=((B, A), torch.uint8))
+        o = dict(steps=torch.empty((B,), dtype=torch.int64, device=dev), flags=torch.empty((B,), dtype=torch.int32, device=dev))
+        for k, (shape, dt) in spec.items():
+            o[k] = torch.empty(shape, dtype=dt, device=dev) if fields is None or k in fields else None
         with torch.cuda.device(dev):
             check(self._lib.dcm_execute_routes(self._h, int(bool(reactive)), *[_ptr(v) for v in o.values()], self._stream()))
+        o = {k: v for k, v in o.items() if v is not None}
         o["summary"] = self.summary()
         return o
 

@@ -74,9 +74,10 @@ struct Lay {
     __host__ __device__ constexpr uint32_t ty() const { return mut_bytes() + 8 * T; }
     __host__ __device__ constexpr uint32_t tdur() const { return mut_bytes() + 16 * T; }
     __host__ __device__ constexpr uint32_t rec_bytes() const { return align16(mut_bytes() + 24 * T); }
-    // LDS image of a record = the record + 32 B: abandonment-log pointer, incremental-update state, count-table pointer
+    // LDS image of a record = the record + 48 B: abandonment-log pointer, incremental-update state, count-table pointer,
+    // dirty-section mask, return-log pointer + capacity
     __host__ __device__ constexpr uint32_t aux() const { return rec_bytes(); }
-    __host__ __device__ constexpr uint32_t lds_rec() const { return rec_bytes() + 32; }
+    __host__ __device__ constexpr uint32_t lds_rec() const { return rec_bytes() + 48; }
     // Scratch of the terminal metrics (calculate_waiting_time), offsets relative to its own base: behind the record in LDS
     // for the persistent kernel of the small shapes, a per-env HBM buffer otherwise (an episode ends once in ~120 decisions;
     // keeping 1.8 KB of LDS per env for it costs k_step 6 of its 27 resident workgroups per CU)
@@ -263,11 +264,37 @@ __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* 
     for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = s[i];
 }
 // record HBM -> LDS: streamed once, keep it out of the way of the observation stores in L2
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void copy16_in(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* s = (const u32x4*)src;
     u32x4* d = (u32x4*)dst;
     for (uint32_t i = lane; i < bytes / 16; i += WAVE) d[i] = __builtin_nontemporal_load(s + i);
+}
+// The same for a compile-time record size: ALL loads are issued before the first LDS write.  (hipcc compiles the loop above
+// into load -> s_waitcnt vmcnt(0) -> ds_write per 1 KiB chunk, i.e. one full HBM round trip per chunk, six in a row for
+// the 20A/50T record: 3.5 us of the lockstep kernel's 13 us wave lifetime in the round-3 phase profile.)
+template <uint32_t BYTES, bool NT = true>
+__device__ __forceinline__ void copy16_in_all(unsigned char* dst, const unsigned char* src, int lane) {
+    constexpr uint32_t N16 = BYTES / 16, CH = (N16 + WAVE - 1) / WAVE, G = 8;   // groups of 8 chunks = 32 VGPRs in flight
+    const u32x4* s = (const u32x4*)src;
+    u32x4* d = (u32x4*)dst;
+#pragma unroll
+    for (uint32_t g = 0; g < CH; g += G) {
+        u32x4 r[G];
+        // no predication at all: the idle lanes of the partial last chunk re-copy the record's last 16 bytes (same value to
+        // the same LDS address), so that the compiler keeps one straight run of global_load_dwordx4 followed by the writes
+#pragma unroll
+        for (uint32_t c = 0; c < G; c++) if (g + c < CH) {
+            const uint32_t i = (g + c) * WAVE + lane;
+            const u32x4* q = s + ((g + c + 1) * WAVE <= N16 ? i : (i < N16 ? i : N16 - 1));
+            if constexpr (NT) r[c] = __builtin_nontemporal_load(q); else r[c] = *q;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < G; c++) if (g + c < CH) {
+            const uint32_t i = (g + c) * WAVE + lane;
+            d[(g + c + 1) * WAVE <= N16 ? i : (i < N16 ? i : N16 - 1)] = r[c];
+        }
+    }
 }
 __device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
     if (lane == 0) {
@@ -320,4 +347,6 @@ struct dcm_env {
     int32_t route_cap = 0, member_cap = 0;
     int32_t vis[4] = {20, 20, 10, 100};  // dynamic-arrival schedule: initial, batch, period, cap (env/task_env.py:567,:221)
     dcm::RouteLog log{nullptr, nullptr, nullptr, 0};   // dcm_set_route_log
+    double* retlog = nullptr;        // dcm_set_return_log: [B][retcap] ring of episode returns
+    int32_t retcap = 0;
 };

@@ -151,6 +151,21 @@ struct Sim {
         }
     }
 
+    // record HBM -> LDS (base): every load in flight before the first LDS write when the layout is a compile-time constant
+    template <bool NT = true>
+    __device__ __forceinline__ void load_record(const unsigned char* rec, int lane) const {
+        if constexpr (CA != 0) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
+        else copy16_in(base, rec, L().rec_bytes(), lane);
+    }
+
+    // optional return log (dcm_set_return_log): this env's ring of `cap` episode returns; pointer kept in the LDS image
+    __device__ __forceinline__ void set_retlog(double* log, int cap, int env_index, int lane) const {
+        if (lane == 0) {
+            *(double**)(base + L().aux() + 32) = log ? log + (size_t)env_index * cap : nullptr;
+            *(int32_t*)(base + L().aux() + 40) = cap;
+        }
+    }
+
     struct AMask { uint64_t w[NAW]; };
     __device__ __forceinline__ static int am_count(const AMask& m) { int n = 0;
 #pragma unroll
@@ -362,13 +377,19 @@ struct Sim {
             const uint32_t info = tinfo()[t];
             const int n = (info >> 16) & 0xFF;
             const double ab = (double)tnab()[t] * mwt;
-            double s = 0., mx = 0.;
-            if (n != 0) {                                                    // :349
-                mx = marr()[t];
-                for (int j = 1; j < n; j++) { const double v = marr()[j * PT_ + t]; mx = v > mx ? v : mx; }
-                if (info & T_FEAS) { for (int j = 0; j < n; j++) s += mx - marr()[j * PT_ + t]; }   // :351
-                else { for (int j = 0; j < n; j++) s += now - marr()[j * PT_ + t]; }               // :354
-            }
+            // all M member slots are read back to back (unused ones hold NaN, which v_max_f64 ignores) instead of walking
+            // the n valid ones with one LDS round trip each
+            double av[M];
+#pragma unroll
+            for (int j = 0; j < M; j++) av[j] = marr()[j * PT_ + t];
+            double mx = av[0];
+#pragma unroll
+            for (int j = 1; j < M; j++) mx = nanmax2(mx, av[j]);             // np.max(arrival) :350
+            mx = n ? mx : 0.;
+            const bool feas = info & T_FEAS;
+            double s = 0.;
+#pragma unroll
+            for (int j = 0; j < M; j++) { const double term = feas ? mx - av[j] : now - av[j]; s = (j < n) ? s + term : s; }   // :351 / :354
             tw()[t] = s + ab;                                                // :351-357
             tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
             const uint64_t ids = mids()[t];
@@ -458,7 +479,16 @@ struct Sim {
 
     // get_episode_reward + perf metrics (env/task_env.py:420-425, worker.py:87,103-108) -> row[8]
     // (header fields are passed by value: a by-reference Hdr would force the caller's header into scratch memory)
-    __device__ __noinline__ bool terminal_metrics(double now, double mwt, int lane, double* __restrict__ row) const {
+    // (called out of line through a by-VALUE copy of the simulator: a noinline member function would take `this`, which
+    //  forces the Sim object -- and with it 64 bytes of scratch memory per lane and two scratch stores in every kernel
+    //  prologue -- into memory)
+    __device__ __noinline__ static bool terminal_metrics(Sim S, double now, double mwt, int lane, double* __restrict__ row) {
+        return S.terminal_metrics_body(now, mwt, lane, row);
+    }
+    __device__ __noinline__ bool terminal_metrics_m(double now, double mwt, int lane, double* __restrict__ row) const {
+        return terminal_metrics_body(now, mwt, lane, row);
+    }
+    __device__ __forceinline__ bool terminal_metrics_body(double now, double mwt, int lane, double* __restrict__ row) const {
         WSYNC();
         const bool over = compute_waits(now, mwt, lane);
         const int T_ = T(), A_ = A();
@@ -474,11 +504,40 @@ struct Sim {
         const double Td = (double)T_, Ad = (double)A_;
         // (numpy's pairwise sum is a single block up to 128 elements: always for agents, A <= DCM_MAX_AGENTS = 128, and for
         //  tasks whenever the layout bounds T by 128)
-        auto tsum = [&](const double* a) { if constexpr (CT != 0 && CT <= 128) return psum_block(a, T_); else return psum<4>(a, T_); };
-        const double m2 = tsum(ts()) / Td;             // np.nanmean(time_start)      worker.py:105
-        const double m3 = psum_block(aw(), A_) / Ad;   // np.mean(agent sum_waiting)  :106
-        const double m4 = psum_block(tdist(), A_);     // np.sum(travel_dist)         :107
-        const double m5 = tsum(tw()) / Td;             // np.mean(task sum_waiting)   :108
+        double m2, m3, m4, m5;
+        if constexpr (CT != 0 && CT <= 128) {
+            // the four sums at once, eight lanes each: lane j of a group owns numpy's accumulator r[j] (np.add.reduce's
+            // unrolled block loop), the three xor-exchanges form ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- fp addition is
+            // commutative, so every lane of the group ends with the same bits -- and the tail elements are added last
+            const int g = (lane >> 3) & 3, j = lane & 7;
+            const double* arr4 = g == 0 ? ts() : g == 1 ? aw() : g == 2 ? tdist() : tw();
+            const int n = (g == 0 || g == 3) ? T_ : A_;
+            double r;
+            if (n < 8) {
+                r = 0.;
+                for (int i = 0; i < n; i++) r += arr4[i];
+            } else {
+                const int nb = n - (n % 8);
+                r = arr4[j];
+                for (int i = 8 + j; i < nb; i += 8) r += arr4[i];
+                r += __shfl_xor(r, 1);
+                r += __shfl_xor(r, 2);
+                r += __shfl_xor(r, 4);
+                for (int i = nb; i < n; i++) r += arr4[i];
+            }
+            auto lane_value = [&](int src) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r), src), __builtin_amdgcn_readlane(__double2loint(r), src));
+            };
+            m2 = lane_value(0) / Td;                   // np.nanmean(time_start)      worker.py:105
+            m3 = lane_value(8) / Ad;                   // np.mean(agent sum_waiting)  :106
+            m4 = lane_value(16);                       // np.sum(travel_dist)         :107
+            m5 = lane_value(24) / Td;                  // np.mean(task sum_waiting)   :108
+        } else {
+            m2 = psum<4>(ts(), T_) / Td;
+            m3 = psum_block(aw(), A_) / Ad;
+            m4 = psum_block(tdist(), A_);
+            m5 = psum<4>(tw(), T_) / Td;
+        }
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[14], __builtin_readcyclecounter() - pt2);
 #endif
@@ -495,12 +554,21 @@ struct Sim {
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt = __builtin_readcyclecounter();
 #endif
-        const bool over = terminal_metrics(h.now, P.mwt, lane, row);
+        #ifdef DCM_TERMINAL_MEMBER
+        const bool over = terminal_metrics_m(h.now, P.mwt, lane, row);
+#else
+        const bool over = terminal_metrics(*this, h.now, P.mwt, lane, row);
+#endif
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[15], __builtin_readcyclecounter() - pt);
 #endif
         h.flags |= DCM_FLAG_DONE | (over ? DCM_FLAG_WAIT_ORDER : 0u);
-        if (lane == 0) ((Hdr*)base)->episodes += 1;   // cold header fields stay in the LDS record
+        if (lane == 0) {                              // cold header fields stay in the LDS record
+            const uint32_t n = ((Hdr*)base)->episodes;
+            ((Hdr*)base)->episodes = n + 1;
+            double* ring = *(double* const*)(base + L().aux() + 32);          // dcm_set_return_log
+            if (ring) ring[n % (uint32_t)*(const int32_t*)(base + L().aux() + 40)] = -h.now;   // reward, env/task_env.py:424
+        }
         h.cur_group = 0;
     }
 
@@ -710,9 +778,11 @@ struct Sim {
             }
         });
         allmasked = __all(allmasked);
+        // (fp64 subtract / convert on all lanes, store by one: single-lane fp64 VALU work is 4x slower on gfx950)
+        const float dxf = (float)(((const Hdr*)base)->depot_x - lx), dyf = (float)(((const Hdr*)base)->depot_y - ly);
         if (lane == 0) {
             if (mask) mask[0] = allmasked ? 0 : 1;                            // worker.py:58-61
-            if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = (float)(((const Hdr*)base)->depot_x - lx); tk[4] = (float)(((const Hdr*)base)->depot_y - ly); }  // :188
+            if (tk) { tk[0] = 0.f; tk[1] = 0.f; tk[2] = 0.f; tk[3] = dxf; tk[4] = dyf; }  // :188
         }
     }
 
@@ -753,7 +823,7 @@ struct Sim {
     __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
-                                                      const RouteLog* log = nullptr, int log_row = 0,
+                                                      RouteLog log = RouteLog{nullptr, nullptr, nullptr, 0}, int log_row = 0,
                                                       bool no_grouping = false, bool check_mask = false,
                                                       bool incremental = false, bool track = false) const {
         const int A_ = A(), T_ = T();
@@ -813,28 +883,32 @@ struct Sim {
             else { tx_ = tx()[k]; ty_ = ty()[k]; }
         }
         PH_MARK(11);
-        // agent_step for every member (:300-324); independent per agent
+        // agent_step for every member (:300-324); independent per agent.  The fp64 arithmetic (distance, sqrt, division) runs
+        // on ALL lanes with a clamped agent index and only the stores are predicated on membership: gfx950 executes an fp64
+        // VALU instruction with fewer than 16 active lanes 4x slower (17 instead of 4.2 clocks, profiles/r03_calib), and a
+        // step moves 1..5 agents.
         double arrv[NAW];
 #pragma unroll
         for (int i = 0; i < NAW; i++) {
             const int a = i * 64 + lane;
-            arrv[i] = 0.0;
+            const int ac = a < A_ ? a : 0;
+            const double d = dist2(ax()[ac], ay()[ac], tx_, ty_);
+            const double travel_time = over_velocity(d);                              // :315 velocity 0.2 (:99)
+            const double td = tdist()[ac] + d;                                        // :317
+            arrv[i] = h.now + travel_time;                                            // :318
             if (a < A_ && ((mm.w[i] >> lane) & 1ull)) {
-                const double d = dist2(ax()[a], ay()[a], tx_, ty_);
-                const double travel_time = over_velocity(d);                          // :315 velocity 0.2 (:99)
-                tdist()[a] += d;                                              // :317
-                arrv[i] = h.now + travel_time;                                // :318
+                tdist()[a] = td;
                 arr()[a] = arrv[i];
                 ax()[a] = tx_; ay()[a] = ty_;                                 // :320
                 cur()[a] = action - 1;                                        // :314 route.append
                 uint32_t ai = ainfo()[a] & ~(A_GRP | A_MEMBER);               // leaves the pending group
                 ai |= (action == 0) ? A_INDEPOT : A_MEMBER;                   // :321-322 listed in the target's members
                 ainfo()[a] = ai;
-                if (log && log->len) {                                        // route.append / arrival_time += (:314,:318)
+                if (log.len) {                                                // route.append / arrival_time += (:314,:318)
                     const size_t o = (size_t)log_row + a;                     // log_row = env index x agents per env
-                    const int c = log->len[o];
-                    if (c < log->cap) { log->task[o * log->cap + c] = (int16_t)(action - 1); log->arrival[o * log->cap + c] = arrv[i]; }
-                    log->len[o] = c + 1;
+                    const int c = log.len[o];
+                    if (c < log.cap) { log.task[o * log.cap + c] = (int16_t)(action - 1); log.arrival[o * log.cap + c] = arrv[i]; }
+                    log.len[o] = c + 1;
                 }
             }
         }
@@ -919,16 +993,22 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, i
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     double *tx = (double*)(rec + L.tx()), *ty = (double*)(rec + L.ty()), *td = (double*)(rec + L.tdur());
     uint32_t* ti = (uint32_t*)(rec + L.tinfo());
+    bool bad = false;
     for (int t = lane; t < eT; t += WAVE) {
         tx[t] = task_xy[((size_t)e * T + t) * 2];
         ty[t] = task_xy[((size_t)e * T + t) * 2 + 1];
         td[t] = dur[(size_t)e * T + t];
-        ti[t] = (uint32_t)req[(size_t)e * T + t] & 0xFF;
+        // requirements outside 1..DCM_MAX_MEMBERS do not fit the member slots (the reference takes any max_coalition_size,
+        // env/task_env.py:71): the env is marked and stays frozen instead of simulating something else
+        const int32_t r = req[(size_t)e * T + t];
+        bad = bad || r < 1 || r > DCM_MAX_MEMBERS;
+        ti[t] = (uint32_t)(r < 1 ? 1 : r > DCM_MAX_MEMBERS ? DCM_MAX_MEMBERS : r);
     }
+    bad = __any(bad);
     if (lane == 0) {
         Hdr* h = (Hdr*)rec;
         h->depot_x = depot[2 * (size_t)e]; h->depot_y = depot[2 * (size_t)e + 1];
-        h->flags = DCM_FLAG_DONE; h->episodes = 0; h->d = 0; h->seed = 0;
+        h->flags = DCM_FLAG_DONE | (bad ? DCM_FLAG_BAD_INSTANCE : 0u); h->episodes = 0; h->d = 0; h->seed = 0;
     }
 }
 
@@ -943,16 +1023,19 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.load_record(rec, lane);
     WSYNC();
     S.set_ablog(ablog, e, S.BA(A), S.BT(T), lane);
+    S.set_retlog(nullptr, 0, e, lane);
     Hdr h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
+    const bool bad_instance = h.flags & DCM_FLAG_BAD_INSTANCE;                // set by dcm_load_instances, survives resets
     S.reset_state(h, lane);
     if (lane < 8) summary[(size_t)e * 8 + lane] = __builtin_nan("");
     PH_DECL;
-    S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
+    if (bad_instance) h.flags = DCM_FLAG_DONE | DCM_FLAG_BAD_INSTANCE;
+    else S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
@@ -970,7 +1053,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     const Lay L = S.L();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.load_record(rec, lane);
     WSYNC();
     Hdr h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
@@ -998,7 +1081,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
                                               uint16_t* ablog, uint32_t mode, const int32_t* sizes, unsigned char* gscr,
-                                              uint32_t max_episodes) {
+                                              uint32_t max_episodes, double* retlog, int retcap) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
@@ -1009,8 +1092,16 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     PHK_DECL;
-    copy16_in(smem, rec, L.rec_bytes(), lane);
+    // the host's per-env inputs are requested first, so that their memory latency hides behind the record copy instead of
+    // being paid at their first use in the middle of the step (phase profile: ~1 us of every wave's critical path)
+    const int act_in = actions[e];
+    const int lead_in = leader_in ? leader_in[e] : -1;
+    const int nf = nfol_in ? nfol_in[e] : -1;
+        // (plain loads, not the non-temporal ones of the persistent kernel: with the record read AND rewritten every launch the
+    //  default L2 policy measured 5.5 % faster at 65 536 envs, same at 4096)
+    S.template load_record<false>(rec, lane);
     S.set_ablog(ablog, e, BA, BT, lane);
+    S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) *S.dirty() = 0;
     WSYNC();
     Hdr h = load_hdr(smem);
@@ -1019,20 +1110,19 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     if (was_active) {
         AMask gm;
         const uint64_t k1 = key1(h.seed, h.d);
-        const int leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, k1, gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
+        const int leader = S.pick_leader(h, lane, lead_in, k1, gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
         PHK_MARK(1);                               // key + leader
         if (leader >= 0) {
-            const int nf = nfol_in ? nfol_in[e] : -1;
             PH_DECL;
-            S.apply_and_advance(h, P, lane, leader, gm, actions[e], k1, nf,
+            S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                &log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true, false, true);
+                                log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true, false, true);
             PHK_MARK(2);                           // apply + updates + advance (+ terminal)
             PHK_INNER();
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
             // the loaded instance, as k_rollout_random does between its episodes (the decision counter keeps running)
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) &&
-                !(h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) &&
+                !(h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE)) &&
                 (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
                 if (log.len) for (int a = lane; a < eA; a += WAVE) log.len[(size_t)e * BA + a] = 0;
                 S.reset_state(h, lane);
@@ -1041,23 +1131,6 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 PHK_MARK(3);                       // auto-reset: reset_state + first event
             }
         }
-    }
-    const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
-    if (want_obs) {
-        WSYNC();
-        float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
-        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
-        uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
-        int leader = -1;
-        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0); }
-        if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
-        else S.write_inactive_obs(lane, ag, tk, mk);
-        if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
-        if (lane == 0) {
-            if (leader_out) leader_out[e] = leader;
-            if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
-        }
-        PHK_MARK(4);                               // next leader + observation stores (issue)
     }
     if (was_active) {
         WSYNC();
@@ -1084,6 +1157,46 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         put(L.tinfo(), (dm & Sim<CA, CT, RS>::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
         PHK_MARK(5);                               // write-back (issue)
     }
+    const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
+    if (want_obs) {
+        WSYNC();
+        float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
+        float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
+        uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
+        int leader = -1;
+        if (!(h.flags & DCM_FLAG_DONE)) { AMask gm; leader = S.pick_leader(h, lane, -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0); }
+        if (leader >= 0) {
+            // The observation rows are built in LDS and leave as contiguous runs.  One lane per row writing its 5 or 6 floats
+            // straight to HBM is a 20/24-byte-strided store (24 partial cache lines per wave instruction, 12 instructions);
+            // staged, the same bytes are 6 fully coalesced instructions.  The staging area is the member-slot section of the
+            // record image (arrival rows + id words): the write-back above has already read it, observe() never does, and
+            // LDS operations of a wave execute in order -- so it costs no LDS (a separate 1.5 KB buffer would cost six
+            // resident workgroups per CU, which is why round 2 measured staging slower).
+            // Only for grids that fill the machine several times over (the HBM-bound regime: 165 -> 158 us at 65 536 envs);
+            // a single round of workgroups is latency-bound and the extra LDS round trip costs it 0.8 us of 24 (4096 envs).
+            const uint32_t need = 24u * (uint32_t)S.A() + 21u * ((uint32_t)S.T() + 1u) + 16u;
+            if (gridDim.x >= 8192u && L.tinfo() - L.marr() >= need) {
+                float* sag = (float*)(smem + L.marr());
+                float* stk = sag + 6 * S.A();
+                uint8_t* smk = (uint8_t*)(stk + 5 * (S.T() + 1));
+                S.observe(h, lane, leader, ag ? sag : nullptr, tk ? stk : nullptr, mk ? smk : nullptr);
+                WSYNC();
+                if (ag) for (int i = lane; i < 6 * S.A(); i += WAVE) ag[i] = sag[i];
+                if (tk) for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) tk[i] = stk[i];
+                if (mk) for (int i = lane; i <= S.T(); i += WAVE) mk[i] = smk[i];
+            } else {
+                S.observe(h, lane, leader, ag, tk, mk);
+            }
+        } else {
+            S.write_inactive_obs(lane, ag, tk, mk);
+        }
+        if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
+        if (lane == 0) {
+            if (leader_out) leader_out[e] = leader;
+            if (active_out) active_out[e] = leader >= 0 ? 1 : 0;
+        }
+        PHK_MARK(4);                               // next leader + observation stores (issue)
+    }
     PHK_TOTAL(6);
 }
 
@@ -1096,7 +1209,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
                                                         const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
-                                                        unsigned char* gscr) {
+                                                        unsigned char* gscr, double* retlog, int retcap) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
@@ -1106,8 +1219,9 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     S.scr = Sim<CA, CT, RS>::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    copy16_in(smem, rec, L.rec_bytes(), lane);
+    S.load_record(rec, lane);
     S.set_ablog(ablog, e, BA, BT, lane);
+    S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
     Hdr h = load_hdr(smem);
@@ -1128,7 +1242,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     const uint64_t d0 = h.d;
     for (int ep = 0; ep < episodes; ep++) {
         if (h.flags & DCM_FLAG_DONE) {  // restart from the loaded instance; d keeps running
-            if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER)) break;
+            if (h.flags & (DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE)) break;
             if (left == 0) break;       // budget spent at an episode boundary: the finished episode's results stay readable
             S.reset_state(h, lane);
             S.advance(h, P, lane, row PH_PASS);
@@ -1147,7 +1261,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
             PH_MARK(2);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, nullptr, 0, false, false, true);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, false, true);
             gd += GAMMA;
             left--;
         }
@@ -1459,6 +1573,14 @@ int dcm_set_route_log(dcm_env* env, int16_t* route_task, double* route_arrival, 
     return DCM_OK;
 }
 
+int dcm_set_return_log(dcm_env* env, double* returns, int32_t cap) {
+    CHECK_HANDLE(env);
+    if ((returns == nullptr) != (cap == 0) || cap < 0)
+        return fail(DCM_ERR_INVALID, "dcm_set_return_log: give a buffer and cap >= 1, or NULL and 0");
+    env->retlog = returns; env->retcap = cap;
+    return DCM_OK;
+}
+
 int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
                 uint8_t* active_out, const int32_t* leader_in, void* stream) {
     CHECK_ENV(env);
@@ -1485,7 +1607,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
                        active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch, \
-                       env->p.auto_reset_episodes)
+                       env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();
@@ -1501,7 +1623,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : env->L.lds_rec()), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
-                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch)
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
     DISPATCH_ENV(env, CALL);
 #undef CALL
     LAUNCH_OK();

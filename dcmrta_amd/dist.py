@@ -98,8 +98,9 @@ class DistContext:
         """True when a process group is up (N > 1, or one rank with DCM_DIST_FORCE_INIT=1): collectives really run."""
         return self._active()
 
-    def all_gather_returns(self, local_returns, async_op=False, n_total=None):
-        """local_returns [B_local] (any float dtype) -> [n_total] on every rank, rank-major order (shard_range blocks).
+    def all_gather_returns(self, local_returns, async_op=False, n_total=None, width=1):
+        """local_returns [B_local * width] (any float dtype; `width` values per env, e.g. the returns of the `width` episodes
+        of a pass) -> [n_total * width] on every rank, rank-major order (shard_range blocks of envs).
         async_op=True returns (out, work): the collective runs on RCCL's stream and the caller's stream keeps
         launching env kernels; call work.wait() before reading `out`.  n_total: number of envs over all ranks when the
         blocks are uneven (n_total % world != 0): the shorter blocks are padded for the collective and trimmed again."""
@@ -107,14 +108,14 @@ class DistContext:
             return (local_returns, None) if async_op else local_returns
         local_returns = local_returns.contiguous()
         n_loc = local_returns.numel()
-        even = n_total is None or n_total == self.world * n_loc
+        even = n_total is None or n_total * width == self.world * n_loc
         if not even:
             # uneven blocks: every rank pads its block to ceil(n_total / world) for the collective; the gathered vector is
             # trimmed back to the shard_range blocks -- after the (still asynchronous) collective has finished
-            pad = -(-n_total // self.world)
+            pad = -(-n_total // self.world) * width
             buf = torch.zeros((pad,), dtype=local_returns.dtype, device=local_returns.device)
             buf[:n_loc] = local_returns
-            sizes = [shard_range(n_total, r, self.world) for r in range(self.world)]
+            sizes = [tuple(width * x for x in shard_range(n_total, r, self.world)) for r in range(self.world)]
 
             def trim(full, out=None):
                 parts = [full[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
@@ -123,7 +124,7 @@ class DistContext:
                 full, work = self.all_gather_returns(buf, async_op=True)
                 if work is None:
                     return trim(full), None
-                out = torch.empty((n_total,), dtype=local_returns.dtype, device=local_returns.device)
+                out = torch.empty((n_total * width,), dtype=local_returns.dtype, device=local_returns.device)
                 return out, _TrimAfterWait(work, lambda: trim(full, out))
             return trim(self.all_gather_returns(buf))
         if async_op and self.backend != "gloo":

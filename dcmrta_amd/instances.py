@@ -116,3 +116,31 @@ def synthetic_routes(req, A, max_task=None):
         for j in range(int(req[t])):
             r[(7 * t + j) % A].append(t + 1)
     return [x + [0] for x in r]
+
+
+def synthetic_route_arrays(req, A, max_task=None):
+    """synthetic_routes for a whole batch as arrays: req int[B,T] -> (routes int32[B,A,cap], route_len int32[B,A]) in the
+    format of dcm_load_routes (0-padded; every agent's list ends with the depot action 0)."""
+    req = np.asarray(req)
+    B, T = req.shape
+    Tm = T if max_task is None else min(T, int(max_task))
+    t_idx = np.repeat(np.arange(Tm), 5)                      # candidate visits (t, j), j < 5 >= any requirement
+    j_idx = np.tile(np.arange(5), Tm)
+    agent = (7 * t_idx + j_idx) % A
+    lens = np.zeros((B, A), np.int64)
+    per_env = []
+    for b in range(B):
+        keep = j_idx < req[b, t_idx]
+        a, t = agent[keep], t_idx[keep]
+        order = np.argsort(a, kind="stable")                 # per agent, tasks stay in ascending id
+        a, t = a[order], t[order]
+        cnt = np.bincount(a, minlength=A)
+        lens[b] = cnt
+        per_env.append((a, t, cnt))
+    cap = int(lens.max()) + 1
+    routes = np.zeros((B, A, cap), np.int32)
+    for b, (a, t, cnt) in enumerate(per_env):
+        start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        pos = np.arange(len(a)) - start[a]
+        routes[b, a, pos] = t + 1
+    return routes, (lens + 1).astype(np.int32)               # + the trailing depot action

@@ -1,8 +1,16 @@
 """Roofline arithmetic of the hot path.
 
 Algorithmic bytes per env step: W = 2*S + O + 4 -- what the lockstep kernel k_step really moves per
-decision.  The persistent kernel keeps the record in LDS and is bound by VALU issue instead: its utilisation is computed
-from SQ counters (profiles/counters.json, written by tools/collect_profile.py from the rocprofv3 CSVs under profiles/).
+decision: that kernel is priced against the HBM peak.  The persistent kernels (k_rollout_random, k_replay) keep the record
+in LDS for whole episodes and are bound by instruction issue instead; their utilisation is computed from SQ instruction
+counters (profiles/counters.json, written by tools/collect_profile.py from the rocprofv3 CSVs under profiles/) priced PER
+INSTRUCTION CLASS with the clocks measured by tools/calib/pmc_calib.hip (profiles/r03_calib):
+
+  * `SQ_ACTIVE_INST_VALU` reads 1.0 per wave64 VALU instruction whatever the instruction costs, so it is an instruction count,
+    not a busy time (round 2 priced every instruction at 4 clocks with it);
+  * measured SIMD time per wave64 instruction at 8 waves per SIMD: fp64 arithmetic / compare / convert, DPP moves,
+    v_readlane, v_mbcnt and VOP3 selects with an SGPR mask 4.25 clocks; 32-bit integer / fp32 / moves 2.35 clocks;
+  * one scalar unit per CU issues 1 SALU instruction per 1.07 clocks (4.27 clocks per SIMD with all four SIMDs issuing).
 """
 import json
 import os
@@ -24,8 +32,18 @@ def algorithmic_bytes_per_step(A, T):
 
 
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E peak (MI355X_MICROARCH.md)
-N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs; one wave64 VALU instruction occupies a SIMD for 4 clocks
+N_CU = 256
+N_SIMD = N_CU * 4              # 256 CUs x 4 SIMDs
 PEAK_CLOCK_HZ = 2.4e9          # peak engine clock (MI355X_MICROARCH.md per-instruction table: "256 CU x 2.4 GHz")
+
+# profiles/r03_calib/table.txt: SIMD clocks per wave64 instruction, throughput at 8 waves per SIMD
+CLOCKS_VALU_64 = 4.25          # v_fma/add/min/cmp_f64, v_cvt_f32_f64, v_mov_b32_dpp, v_readlane, v_mbcnt, v_cndmask_e64 (SGPR mask)
+CLOCKS_VALU_32 = 2.35          # v_add_u32, v_fma_f32, v_mov_b32
+CLOCKS_SALU_PER_CU = 1.07      # s_add_u32 / s_mul_i32: 4.27 clocks per SIMD-instruction with 4 SIMDs sharing the scalar unit
+CALIB_SOURCE = "profiles/r03_calib/table.txt"
+# SQ_INSTS_VALU_* classes that the calibration prices at CLOCKS_VALU_64
+F64_CLASS_COUNTERS = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                      "SQ_INSTS_VALU_CVT")
 
 _COUNTERS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "counters.json")
 
@@ -37,3 +55,43 @@ def load_counters(key):
             return json.load(f).get(key)
     except (OSError, ValueError):
         return None
+
+
+def issue_roofline(c, units_per_step, step_s, unit="decision"):
+    """Issue-bound roofline of a persistent (LDS-resident) kernel from its per-`unit` instruction counters `c`.
+
+    VALU pipe time per unit = sum over instruction classes of count x measured clocks.  The class counters cover the fp64
+    arithmetic and conversions; the remaining instructions (moves, selects, compares, integer and cross-lane work) are priced
+    at the 32-bit rate for `frac` (an estimate that can only be low: part of them are 4-clock instructions) and at the 64-bit
+    rate for `frac_hi` (every VALU instruction at 4.25 clocks -- the upper bound; round 2's figure).  Both are fractions of
+    1024 SIMDs x 2.4 GHz.  `salu_issue_frac`: scalar-unit issue slots used, 256 CUs x 2.4 GHz / 1.07 clocks per instruction."""
+    n_valu = c[f"SQ_INSTS_VALU_per_{unit}"]
+    have_classes = all(f"{k}_per_{unit}" in c for k in F64_CLASS_COUNTERS)
+    n64 = sum(c[f"{k}_per_{unit}"] for k in F64_CLASS_COUNTERS) if have_classes else 0.0
+    lo = CLOCKS_VALU_64 * n64 + CLOCKS_VALU_32 * (n_valu - n64)
+    hi = CLOCKS_VALU_64 * n_valu
+    peak = N_SIMD * PEAK_CLOCK_HZ
+    per_s = units_per_step / step_s
+    out = {"bound": "valu_issue", "achieved": lo * per_s / 1e9, "peak": peak / 1e9, "unit": "G SIMD-clocks/s (VALU pipe busy)",
+           "frac": lo * per_s / peak, "frac_hi": hi * per_s / peak,
+           "pricing": {"clocks_fp64_class": CLOCKS_VALU_64, "clocks_other": CLOCKS_VALU_32, "fp64_class_insts_per_" + unit: n64,
+                       "valu_insts_per_" + unit: n_valu, "class_counters": have_classes, "calibration": CALIB_SOURCE,
+                       "note": "frac prices the fp64-class instructions at 4.25 clocks and all others at 2.35 (low estimate); "
+                               "frac_hi prices every VALU instruction at 4.25"}}
+    n_salu = c.get(f"SQ_INSTS_SALU_per_{unit}")
+    if n_salu is not None:
+        out["salu_issue_frac"] = n_salu * CLOCKS_SALU_PER_CU * per_s / (N_CU * PEAK_CLOCK_HZ)
+        out["salu_insts_per_" + unit] = n_salu
+    if f"SQ_THREAD_CYCLES_VALU_per_{unit}" in c and f"SQ_ACTIVE_INST_VALU_per_{unit}" in c:
+        out["lane_util"] = c[f"SQ_THREAD_CYCLES_VALU_per_{unit}"] / (64.0 * c[f"SQ_ACTIVE_INST_VALU_per_{unit}"])
+    wave = c.get(f"SQ_WAVE_CYCLES_per_{unit}")
+    if wave:
+        out["wave_time_split"] = {k: c[f"{name}_per_{unit}"] / wave for k, name in
+                                  (("executing", "SQ_ACTIVE_INST_ANY"), ("parked_on_waitcnt", "SQ_WAIT_ANY"),
+                                   ("issue_stalled", "SQ_WAIT_INST_ANY")) if f"{name}_per_{unit}" in c}
+    return out
+
+
+def staleness(c, build_id):
+    """True when the counter set was measured on another build of the kernels than the loaded library (dcm_build_id)."""
+    return c.get("build_id") != build_id

@@ -130,7 +130,7 @@ class BatchedRunner:
         rewards into the batch (the reference would step onto the masked task; its policy contract never does,
         attention.py:74-76).  Truncated episodes (zero-decider guard) are counted and reported."""
         flags = env.status()["flags"]
-        bad = (flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER)) != 0
+        bad = (flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER | _lib.FLAG_BAD_INSTANCE)) != 0
         n_bad = int(bad.sum())
         if n_bad:
             first = int(torch.nonzero(bad)[0])

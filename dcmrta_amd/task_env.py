@@ -119,7 +119,7 @@ class TaskEnv:
         self._members = [[int(m) for m in mem[t] if m >= 0] for t in range(self.tasks_num)]
         ab = self._env.abandoned_counts()[0].cpu().numpy()
         self._abandoned = [[a for a in range(self.agents_num) for _ in range(int(ab[a, t]))] for t in range(self.tasks_num)]
-        if self._flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER):
+        if self._flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER | _lib.FLAG_BAD_INSTANCE):
             raise RuntimeError(f"env error flags {self._flags:#x}")
         if self._flags & _lib.FLAG_TRUNCATED:
             raise RuntimeError("every agent is at the depot while a task can never become feasible: the reference "

@@ -62,6 +62,8 @@ typedef enum {
                                   * (65535; RL mode) or, in route replay, an agent was moved to abandoned_agent lists more than 16 \
                                   * times: that agent's sum_waiting_time then adds the excess max_waiting_time terms last instead \
                                   * of in task order (env/task_env.py:363-364), i.e. it may differ in the last bits */
+#define DCM_FLAG_BAD_INSTANCE 256u /* dcm_load_instances found a requirement outside 1..DCM_MAX_MEMBERS (checked on the device): \
+                                    * the env never starts (DONE from dcm_reset on) until a valid instance is loaded */
 #define DCM_FLAG_TYPE_ERROR 64u /* route replay: the reference raises TypeError here (env/task_env.py:220, pre_set_route None) */
 
 /* dcm_params.flags: individual selection (Worker.run_test_IS, worker.py:159-198, skips get_unique_group) -- all agents
@@ -101,7 +103,8 @@ int dcm_create(const dcm_params *params, dcm_env **out);
 int dcm_destroy(dcm_env *env);
 
 /* generate_env outputs (env/task_env.py:57-114) handed over as arrays:
- * depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] i32 in 1..DCM_MAX_MEMBERS, dur[B,T] f64. */
+ * depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] i32 in 1..DCM_MAX_MEMBERS, dur[B,T] f64.
+ * req is validated on the device: an env with a requirement outside the range gets DCM_FLAG_BAD_INSTANCE and stays frozen. */
 int dcm_load_instances(dcm_env *env, const double *depot, const double *task_xy, const int32_t *req,
                        const double *dur, void *stream);
 
@@ -155,6 +158,12 @@ int dcm_step(dcm_env *env, const int32_t *actions, const int32_t *leader_in, con
  * outlive its use; all NULL disables.  dcm_reset zeroes route_len; entries beyond cap are counted but not stored.
  * (dcm_rollout_random does not log: use the lockstep API when trajectories are wanted.) */
 int dcm_set_route_log(dcm_env *env, int16_t *route_task, double *route_arrival, int32_t *route_len, int32_t cap);
+
+/* Optional log of EVERY episode's return (reward = -makespan, env/task_env.py:424; what worker.py:87 reads per episode):
+ * returns[B,cap] f64, caller-owned device memory that must outlive its use; NULL / 0 disables.  The k-th episode an env
+ * finishes since dcm_reset (dcm_rollout_random, dcm_step) writes returns[b, k mod cap] -- a ring, so a caller that plays
+ * `cap` episodes per call finds all of them after the call (dcm_summary keeps only the last one).  Host-side setter. */
+int dcm_set_return_log(dcm_env *env, double *returns, int32_t cap);
 
 /* Config-2 hot path: every env plays `episodes` complete episodes under the uniform-random valid
  * policy inside ONE persistent launch (worker.py:45-87 with the action drawn from slot 1 of the

@@ -69,8 +69,15 @@ def main():
         (30, 120, (20, 20, 10, 120), "synthetic"), (30, 120, (30, 30, 4, 120), "random"), (13, 37, (8, 4, 3, 37), "random"),
         (50, 200, (40, 40, 10, 200), "synthetic"), (50, 200, (20, 20, 2, 200), "random"), (10, 64, (16, 16, 16, 48), "random"),
         (100, 500, (100, 100, 10, 500), "synthetic"), (100, 500, (20, 20, 10, 100), "synthetic100"),
+        (30, 120, (30, 30, 4, 120), "random_all"), (13, 37, (8, 4, 3, 37), "random_all"), (50, 200, (20, 20, 2, 200), "random_all"),
+        (20, 50, (7, 13, 3, 50), "random_all"),
     ]
+    out_path = os.path.join(HERE, "replay_schedule.json")
+    if os.path.exists(out_path) and "--append" in sys.argv:      # keep the cases already generated, add the new specs
+        cases = json.load(open(out_path))
     for ci, (A, T, sched, style) in enumerate(specs):
+        if ci < len(cases):
+            continue
         TaskEnv = patched_taskenv(*sched)
         env = TaskEnv((A, A), (T, T), 1, 5, seed=500 + ci)
         ia = mg.instance_arrays(env)
@@ -81,6 +88,8 @@ def main():
         else:
             import make_golden_extra as mge
             routes = mge.random_routes(rng, A, T, ia["req"])
+            if style == "random_all":        # every agent has a route (no pre_set_route None -> no TypeError at :220)
+                routes = [r if r is not None else [0] for r in routes]
         env.reactive_planning = True
         for a, r in enumerate(routes):
             if r is not None:
@@ -104,7 +113,7 @@ def main():
             signal.alarm(0)
         print("schedule", ci, A, T, sched, style, case["status"], case.get("result", {}).get("metrics", [None, None])[:2], flush=True)
         cases.append(case)
-    with open(os.path.join(HERE, "replay_schedule.json"), "w") as f:
+    with open(out_path, "w") as f:
         json.dump(cases, f)
 
 

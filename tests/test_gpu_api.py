@@ -384,3 +384,43 @@ def test_auto_reset_with_individual_selection(gpu_device):
             seen = eps.clone()
     assert (env.episodes() == 3).all() and not bool(obs.active.any())
     assert torch.equal(env.status()["decisions"], 3 * n1) and torch.equal(env.summary(), want)
+
+
+def test_requirements_are_validated_on_the_device(gpu_device):
+    """The C ABI itself refuses a requirement outside 1..DCM_MAX_MEMBERS (the Python wrapper checks too, but a maintainer binds
+    the ABI): the env is flagged by dcm_load_instances and never starts; its neighbours are untouched."""
+    import ctypes as C
+    import torch
+    from dcmrta_amd import _lib
+    from dcmrta_amd.batched_env import BatchedTaskEnv, _ptr
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 6, 5, 8
+    inst = generate_batch(B, A, T, base_seed=5)
+    req = inst["req"].copy()
+    req[2, 3] = 7
+    req[4, 0] = 0
+    env = BatchedTaskEnv(B, A, T, device=gpu_device)
+    dev = env.device
+    d = torch.as_tensor(inst["depot"]).to(dev); xy = torch.as_tensor(inst["task_xy"]).to(dev)
+    rq = torch.as_tensor(req, dtype=torch.int32).to(dev); du = torch.as_tensor(inst["dur"]).to(dev)
+    _lib.check(env._lib.dcm_load_instances(env._h, _ptr(d), _ptr(xy), _ptr(rq), _ptr(du), env._stream()))
+    obs = env.reset(env_seeds(1, 0, B))
+    flags = env.status()["flags"].cpu().numpy()
+    bad = np.array([False, False, True, False, True, False])
+    assert ((flags & _lib.FLAG_BAD_INSTANCE) != 0).tolist() == bad.tolist()
+    assert (obs.active.cpu().numpy() == ~bad).all()
+    steps = env.rollout_random(episodes=1).cpu().numpy()
+    assert (steps[bad] == 0).all() and (steps[~bad] > 0).all()
+    flags = env.status()["flags"].cpu().numpy()
+    assert ((flags & _lib.FLAG_BAD_INSTANCE) != 0).tolist() == bad.tolist()
+    # the valid envs played exactly what they play in a clean batch
+    clean = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    clean.reset(env_seeds(1, 0, B), observe=False)
+    ref = clean.rollout_random(episodes=1).cpu().numpy()
+    assert (steps[~bad] == ref[~bad]).all()
+    assert np.array_equal(env.summary().cpu().numpy()[~bad], clean.summary().cpu().numpy()[~bad])
+    # a valid instance clears the mark
+    env.load_instances(**inst)
+    env.reset(env_seeds(1, 0, B), observe=False)
+    assert not (env.status()["flags"].cpu().numpy() & _lib.FLAG_BAD_INSTANCE).any()

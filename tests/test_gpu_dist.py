@@ -45,8 +45,11 @@ def test_single_gpu_bench_contract_line(gpu_device):
     r = j["roofline"]
     # the persistent kernel is issue-bound: frac = VALU-busy SIMD-cycles / available SIMD-cycles, a utilisation (<= 1)
     assert r["bound"] == "valu_issue" and r["kernel"] == "k_rollout_random" and r["peak"] == 1024 * 2.4
-    assert r["frac"] is not None and 0.05 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["frac"] is not None and 0.05 < r["frac"] <= r["frac_hi"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["salu_issue_frac"] <= 1.0 and r["pricing"]["calibration"].startswith("profiles/")
     assert 0.0 < r["lane_util"] <= 1.0 and r["counters_source"].startswith("profiles/")
+    # the counters are tied to the kernel build they were measured on: a profile of another build is reported, not hidden
+    assert r["stale"] == (r["counters_build_id"] != r["build_id"]) and len(r["build_id"]) == 16
     assert r["traffic"] is None or r["traffic"] > 0
     assert r["hbm"]["frac"] is None or 0.0 < r["hbm"]["frac"] <= 1.0          # measured HBM bytes: far below the peak
     assert r["w_scored"]["algorithmic_bytes_per_step"] == 13203
@@ -89,3 +92,29 @@ def test_config4_strong_scaling_line(gpu_device):
     assert j["config"]["envs_total"] == 1001 and j["config"]["envs_per_gpu"] == 501      # uneven shards: 501 + 500
     per_pass = j["value"] * j["ms_per_step"] / 1e3
     assert 1001 * 200 < per_pass < 1001 * 500                                             # ~320 decisions per episode
+
+
+def test_config5_replay_line(gpu_device):
+    """bench.py --config 5 (BASELINE configs[4]: 100A/500T route replay with dynamic task arrivals, sharded over the ranks), two
+    ranks on the one GPU over gloo with a reduced env count; and the N = 1 line with the oracle's replay as cpu_baseline."""
+    env = dict(os.environ, DCM_FORCE_DEVICE="0", DCM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "2", "--warmup", "1",
+           "--envs", "301"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["agents"] == 100 and j["config"]["tasks"] == 500
+    assert j["config"]["envs_total"] == 301 and j["config"]["envs_per_gpu"] == 151 and j["config"]["visibility"] == [20, 20, 10, 100]
+    assert j["roofline"]["kernel"] == "k_replay" and "agent_step" in j["config"]["step_definition"]
+    per_pass = j["value"] * j["ms_per_step"] / 1e3
+    assert 301 * 100 < per_pass < 301 * 2000          # every agent takes a few steps (routes over the 100 visible tasks + depot)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--envs", "256", "--steps", "2",
+                          "--warmup", "1", "--visibility", "100,100,10,500"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert "GENERALISED" in j["config"]["workload"] and j["config"]["visibility"] == [100, 100, 10, 500]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "execute_by_route" in c["sample"]

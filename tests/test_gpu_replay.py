@@ -109,3 +109,52 @@ def test_random_route_replays_known_answers(gpu_device, golden_dir):
             n_ok += 1
         env.close()
     assert n_ok >= 15
+
+
+def test_generalised_visibility_schedule(gpu_device, golden_dir, oracle_lib):
+    """dcm_set_visibility: the reactive replay under other dynamic-arrival constants than the reference's 20 / 20 / 10 / 100,
+    against the reference run with those constants (tests/golden/replay_schedule.json) and, at BASELINE config-5 size with a
+    schedule under which all 500 tasks appear, against the oracle on a small batch."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import generate_batch
+    from test_oracle_golden import schedule_cases
+    n_ok = 0
+    for c, inst in schedule_cases(golden_dir):
+        env = BatchedTaskEnv(1, c["A"], c["T"], device=gpu_device)
+        env.load_instances(inst["depot"][None], inst["task_xy"][None], inst["req"][None], inst["dur"][None])
+        env.set_visibility(*c["schedule"])
+        env.load_routes([c["routes"]], member_cap=16)
+        out = env.execute_routes(reactive=True)
+        flags = int(out["flags"].cpu().numpy()[0])
+        name = (c["A"], c["T"], tuple(c["schedule"]))
+        if c["status"] == "type_error":
+            assert flags & 64, name
+        elif c["status"] == "no_termination":
+            assert flags & 4 and not flags & 64, name
+        else:
+            assert not flags & (4 | 16 | 64), name
+            for k in KEYS_EXACT:
+                exp = np.asarray(c["result"][k])
+                assert np.array_equal(out[k][0].cpu().numpy().astype(exp.dtype), exp), (name, k)
+            assert np.array_equal(out["summary"][0].cpu().numpy()[2:8], np.asarray(c["result"]["metrics"])), name
+            n_ok += 1
+        env.close()
+    assert n_ok >= 6
+    # config-5 size, every task routed, all of them eventually visible
+    B, A, T = 3, 100, 500
+    inst = generate_batch(B, A, T, base_seed=77)
+    rl = [synthetic_routes(inst["req"][b], A) for b in range(B)]
+    env = BatchedTaskEnv(B, A, T, device=gpu_device)
+    env.load_instances(**inst)
+    env.set_visibility(100, 100, 10, 500)
+    env.load_routes(rl, member_cap=8)
+    out = env.execute_routes(reactive=True)
+    assert not (out["flags"].cpu().numpy() & 0x78).any()
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        o.set_visibility(100, 100, 10, 500)
+        for a, r in enumerate(rl[b]):
+            o.pre_set_route(r, a)
+        _check(out, b, o.execute_by_route(True), f"all-visible schedule env{b}")
+    with pytest.raises(Exception):
+        env.set_visibility(20, 0, 10, 100)

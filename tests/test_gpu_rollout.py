@@ -212,3 +212,48 @@ def test_ragged_batch_per_decision_outputs(gpu_device, oracle_lib):
     sm = env.summary().cpu().numpy()
     for b in range(B):
         assert steps[b] + steps2[b] == refs[b]["n_steps"] and sm[b, 0] == refs[b]["reward"], b
+
+
+def test_return_log_keeps_every_episode(gpu_device, oracle_lib):
+    """dcm_set_return_log: one 3-episode launch leaves all three episode returns in the ring (dcm_summary keeps the last one
+    only) -- the per-episode return vector bench.py all-gathers; checked against three one-episode launches of
+    a twin handle and, for the first episode, the oracle.  Also through the lockstep API with auto-reset."""
+    import torch
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 24, 20, 50
+    inst = generate_batch(B, A, T, base_seed=3)
+    seeds = env_seeds(9, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    ring = env.enable_return_log(3)
+    env.reset(seeds, observe=False)
+    env.rollout_random(episodes=3)
+    twin = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    twin.reset(seeds, observe=False)
+    per_episode = []
+    for _ in range(3):
+        twin.rollout_random(episodes=1)
+        per_episode.append(twin.summary()[:, 0].cpu().numpy().copy())
+    got = ring.cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(got[:, k], per_episode[k]), k
+    assert np.array_equal(got[:, 2], env.summary()[:, 0].cpu().numpy())
+    for b in range(0, B, 5):
+        ref = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b]) \
+            .rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, record=False)
+        assert got[b, 0] == ref["reward"]
+    # a fourth episode wraps around to column 0
+    env.rollout_random(episodes=1)
+    assert np.array_equal(ring.cpu().numpy()[:, 0], env.summary()[:, 0].cpu().numpy())
+    # lockstep API with auto-reset: the ring fills as episodes end
+    ls = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True, auto_reset_episodes=2).load_instances(**inst)
+    ring2 = ls.enable_return_log(2)
+    obs = ls.reset(seeds)
+    for _ in range(600):
+        if not bool(obs.active.any()):
+            break
+        obs = ls.step(torch.argmax((~obs.mask).to(torch.int32), dim=1).int())
+    assert not bool(obs.active.any())
+    r2 = ring2.cpu().numpy()
+    assert not np.isnan(r2).any() and np.array_equal(r2[:, 1], ls.summary()[:, 0].cpu().numpy())

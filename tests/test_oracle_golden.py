@@ -232,3 +232,47 @@ def test_random_route_replays(oracle_lib, golden_dir):
                 exp = np.asarray(v)
                 assert np.array_equal(np.asarray(ref[k]).astype(exp.dtype), exp, equal_nan=True), (c["A"], c["T"], c["reactive"], k)
     assert seen["ok"] >= 15 and seen["type_error"] >= 10 and seen["no_termination"] >= 4
+
+
+def schedule_cases(golden_dir):
+    """tests/golden/replay_schedule.json (make_golden_schedule.py): replays of the reference with its four dynamic-arrival
+    constants substituted (env/task_env.py:567, :221) -> (case, instance dict) pairs."""
+    from dcmrta_amd.instances import generate_instance
+    out = []
+    for c in json.load(open(os.path.join(golden_dir, "replay_schedule.json"))):
+        inst = generate_instance(c["A"], c["T"], c["inst_seed"])
+        assert int(inst["req"].sum()) == c["req_sum"]
+        out.append((c, inst))
+    return out
+
+
+def test_generalised_visibility_schedule(oracle_lib, golden_dir):
+    """The parametrised schedule (orc_set_visibility) against the reference run with the same four constants: every terminal
+    array bit for bit, incl. a schedule under which all 500 tasks of a 100A/500T instance become visible, the reference's own
+    constants (an identity check of the harness), TypeError cases and one the reference never finishes."""
+    seen = {"ok": 0, "type_error": 0, "no_termination": 0}
+    for c, inst in schedule_cases(golden_dir):
+        o = oracle_lib.OracleEnv(c["A"], c["T"]).load(inst["depot"], inst["task_xy"], inst["req"], inst["dur"])
+        o.set_visibility(*c["schedule"])
+        for a, r in enumerate(c["routes"]):
+            if r is not None:
+                o.pre_set_route(r, a)
+        try:
+            ref = o.execute_by_route(True)
+            status = "no_termination" if ref["truncated"] else "ok"
+        except TypeError:
+            status = "type_error"
+        assert status == c["status"], (c["A"], c["T"], c["schedule"])
+        seen[status] += 1
+        if status == "ok":
+            for k, v in c["result"].items():
+                exp = np.asarray(v)
+                assert np.array_equal(np.asarray(ref[k]).astype(exp.dtype), exp, equal_nan=True), (c["A"], c["T"], c["schedule"], k)
+    assert seen["ok"] >= 6
+
+
+def test_visibility_schedule_validation(oracle_lib):
+    o = oracle_lib.OracleEnv(3, 4)
+    for bad in ((-1, 20, 10, 100), (20, 0, 10, 100), (20, 20, 0, 100), (20, 20, 10, 19)):
+        with pytest.raises(ValueError):
+            o.set_visibility(*bad)

@@ -42,7 +42,11 @@ W = 2 * (64 + 48 * A + 96 * T) + 24 * A + 21 * (T + 1) + 4
 traffic = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
 path = "profiles/counters.json"
 allc = json.load(open(path)) if os.path.exists(path) else {}
-allc[f"k_step:{B}x{A}A{T}T"] = dict(source=out, avg_launch_us=avg_ns / 1e3, hbm_bytes_per_launch=traffic,
+build_id = None
+for l in open(base + "stats.log"):
+    if l.startswith("build_id "):
+        build_id = l.split()[1]
+allc[f"k_step:{B}x{A}A{T}T"] = dict(source=out, avg_launch_us=avg_ns / 1e3, hbm_bytes_per_launch=traffic, build_id=build_id,
                                     algorithmic_bytes_per_launch=B * W, traffic_over_algorithmic=traffic / (B * W),
                                     hbm_frac_rocprof=B * W / (avg_ns * 1e-9) / 8e12,
                                     **{k + "_per_launch": v for k, v in tot.items()})

@@ -39,9 +39,14 @@ cfg = bench["config"]
 passes = bench["steps"] + bench["warmup"]
 decisions = cfg["decisions_per_step_per_gpu"] * bench["steps"] + cfg["decisions_in_warmup_per_gpu"]
 rows, meta, tot = [], None, {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sqa", "pmc_sqb"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sqa", "pmc_sqb", "pmc_cls", "pmc_cls2"):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(find(f"{d}/**/*counter_collection.csv"))):
+    hits = glob.glob(base + f"{d}/**/*counter_collection.csv", recursive=True)
+    if not hits:
+        if d.startswith("pmc_cls"):
+            continue                      # instruction-class passes are optional
+        raise SystemExit(f"missing {base}{d}")
+    for r in csv.DictReader(open(hits[0])):
         if kern in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = (r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"], r["Grid_Size"], r["Workgroup_Size"])
@@ -56,12 +61,17 @@ with open(f"{dst}/pmc_{kern}.csv", "w") as f:
     f.write("# command: %s\n" % open(base + "command.txt").read().strip())
     f.write("# passes %d (incl. warm-up), decisions in all passes %d\n" % (passes, decisions))
 per = {f"{k}_per_decision": v / decisions for k, v in tot.items()}
-key = f"{kern}:{cfg['agents']}A{cfg['tasks']}T"
+vis = cfg.get("visibility")
+vis_tag = "" if not vis or list(vis) == [20, 20, 10, 100] else ":vis" + "-".join(str(v) for v in vis)
+key = f"{kern}:{cfg['agents']}A{cfg['tasks']}T{vis_tag}"
 entry = dict(per, source=f"profiles/{name}/pmc_{kern}.csv", envs_per_gpu=cfg["envs_per_gpu"], streams=cfg.get("streams_per_gpu", 1),
              decisions_profiled=decisions,
+             # dcm_build_id of the library that was profiled: bench.py reports "stale" when it runs another build
+             build_id=bench["roofline"].get("build_id"),
              hbm_bytes_per_decision=(2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / decisions,
-             note="FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (16 B/lane coalesced record loads); SQ_* in quad-cycles "
-                  "(profiles/r02_calib)")
+             note="FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (16 B/lane coalesced record loads); SQ_WAVE_CYCLES / SQ_WAIT_* "
+                  "in quad-cycles, SQ_ACTIVE_INST_VALU = instruction count (profiles/r03_calib); a 'decision' of k_replay is one "
+                  "agent_step call")
 path = "profiles/counters.json"
 allc = json.load(open(path)) if os.path.exists(path) else {}
 allc[key] = entry

@@ -12,6 +12,8 @@ from dcmrta_amd.choice import env_seeds
 from dcmrta_amd.instances import generate_batch
 from dcmrta_amd.roofline import algorithmic_bytes_per_step
 
+from dcmrta_amd import _lib
+print("build_id", _lib.build_id())
 B, A, T, N = (int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (65536, 20, 50, 60)))
 env = BatchedTaskEnv(B, A, T).load_instances(**generate_batch(B, A, T, 0))
 obs = env.reset(env_seeds(0, 0, B))
