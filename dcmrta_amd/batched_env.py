@@ -42,7 +42,7 @@ def _ptr(t):
 
 class BatchedTaskEnv:
     def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
-                 individual_selection=False, auto_reset=False, auto_reset_episodes=0):
+                 individual_selection=False, auto_reset=False, auto_reset_episodes=0, strict_mask=False):
         self._h = None
         self._lib = _lib.load()
         self.device = torch.device(device)
@@ -57,7 +57,9 @@ class BatchedTaskEnv:
         # individual_selection: Worker.run_test_IS (worker.py:159-198) -- deciders are not grouped by location
         # auto_reset: step() restarts an env from its instance in the call that ends its episode (DCM_PARAM_AUTO_RESET): the
         # batch stays full; summary() holds each env's last finished episode, episodes() counts them
-        flags = (1 if individual_selection else 0) | (2 if auto_reset else 0)
+        # strict_mask: freeze an env whose host-supplied action is on a masked task (DCM_PARAM_STRICT_MASK) instead of
+        # simulating it like the reference's TaskEnv.step does
+        flags = (1 if individual_selection else 0) | (2 if auto_reset else 0) | (4 if strict_mask else 0)
         # auto_reset_episodes: an env stops restarting after that many finished episodes (0 = never)
         p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, flags, int(auto_reset_episodes))
         h = C.c_void_p()

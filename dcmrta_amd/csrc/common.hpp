@@ -24,11 +24,14 @@ struct Hdr {  // 64 B header of an env record
     uint64_t d;            // running decision counter (key of the choice protocol)
     double depot_x, depot_y;  // depot['location'] :111
     uint32_t flags;        // DCM_FLAG_*
-    int32_t cur_group;     // 1-based index of the group now deciding (worker.py:52), 0 = none
-    int32_t n_groups;      // groups of the current event (env/task_env.py:291-298)
-    int32_t empty_passes;  // consecutive zero-decider events (guard)
-    uint32_t ep_steps;     // decisions in the current episode
+    uint32_t groups;       // packed in memory: bits 0-7 cur_group, 8-15 n_groups, 16-23 empty_passes (see HdrRegs)
     uint32_t episodes;     // finished episodes since dcm_reset
+    uint32_t reserved;
+    double max_arrival;    // largest arrival time any agent_step of this episode has appended to an arrival_time list: the
+                           // "max(arrival_time)" over all agents that next_decision / check_finished return as the time when
+                           // nobody can decide any more (env/task_env.py:286,369).  With valid actions every list is
+                           // monotone and this equals the maximum of the agents' last arrivals; a host-supplied action on a
+                           // masked task can release an agent before it arrives, after which its list is not monotone
 };
 static_assert(sizeof(Hdr) == 64, "header must be 64 bytes");
 
@@ -126,14 +129,22 @@ __device__ __forceinline__ uint64_t uni(uint64_t v) {
 }
 __device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni((uint64_t)__double_as_longlong(v))); }
 
-__device__ __forceinline__ Hdr load_hdr(const unsigned char* p) {
+// The hot header fields as the kernels carry them (wave-uniform, in SGPRs); depot / episodes / max_arrival stay in the LDS record
+struct HdrRegs {
+    double now;
+    uint64_t seed, d;
+    uint32_t flags;
+    int32_t cur_group;     // 1-based index of the group now deciding (worker.py:52), 0 = none
+    int32_t n_groups;      // groups of the current event (env/task_env.py:291-298)
+    int32_t empty_passes;  // consecutive zero-decider events (guard)
+};
+__device__ __forceinline__ HdrRegs load_hdr(const unsigned char* p) {
     const Hdr* q = (const Hdr*)p;
-    Hdr h;
-    // hot fields only: depot / episodes / ep_steps stay in the LDS record (keeps the SGPR budget small)
+    HdrRegs h;
     h.now = uni(q->now); h.seed = uni(q->seed); h.d = uni(q->d);
-    h.flags = uni(q->flags); h.cur_group = uni(q->cur_group); h.n_groups = uni(q->n_groups);
-    h.empty_passes = uni(q->empty_passes);
-    h.depot_x = 0.0; h.depot_y = 0.0; h.ep_steps = 0; h.episodes = 0;
+    h.flags = uni(q->flags);
+    const uint32_t g = uni(q->groups);
+    h.cur_group = (int32_t)(g & 0xFFu); h.n_groups = (int32_t)((g >> 8) & 0xFFu); h.empty_passes = (int32_t)((g >> 16) & 0xFFu);
     return h;
 }
 
@@ -296,11 +307,11 @@ __device__ __forceinline__ void copy16_in_all(unsigned char* dst, const unsigned
         }
     }
 }
-__device__ __forceinline__ void store_hdr(const Hdr& h, int lane) {
+__device__ __forceinline__ void store_hdr(const HdrRegs& h, int lane) {
     if (lane == 0) {
         Hdr* q = (Hdr*)smem;
-        q->now = h.now; q->seed = h.seed; q->d = h.d; q->flags = h.flags; q->cur_group = h.cur_group;
-        q->n_groups = h.n_groups; q->empty_passes = h.empty_passes;
+        q->now = h.now; q->seed = h.seed; q->d = h.d; q->flags = h.flags;
+        q->groups = (uint32_t)h.cur_group | ((uint32_t)h.n_groups << 8) | ((uint32_t)h.empty_passes << 16);
     }
 }
 

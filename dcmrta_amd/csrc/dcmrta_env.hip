@@ -20,6 +20,7 @@
 // Reference restated: env/task_env.py (TaskEnv) and worker.py:41-112 (the rollout loop).
 // Every device function cites the lines it follows.
 #include <cstdlib>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -223,7 +224,7 @@ struct Sim {
     // bit 6 member ids, bit 7 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
     static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_IDS = 1u << 6, DIRTY_NAB = 1u << 7, DIRTY_ALL = 0xFFu;
     __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + L().aux() + 24); }
-    __device__ __forceinline__ void task_update(const Hdr& h, const KP& P, int lane, int only = -1, bool track = false) const {
+    __device__ __forceinline__ void task_update(const HdrRegs& h, const KP& P, int lane, int only = -1, bool track = false) const {
         const double now = h.now, mwt = P.mwt;
         const int T_ = T(), PT_ = PT();
         bool allf = true, touched = false;
@@ -344,7 +345,7 @@ struct Sim {
     // ------------------------------------------------------------------------------ agent_update
     // env/task_env.py:207-243 (non-reactive branch :226).  `agent in current_task['members']` (:230) is the
     // cached A_MEMBER bit (set by agent_step, cleared when task_update drops the agent from that task).
-    __device__ __forceinline__ void agent_update(const Hdr& h, const KP& P, int lane) const {
+    __device__ __forceinline__ void agent_update(const HdrRegs& h, const KP& P, int lane) const {
         const double now = h.now;
         for_agents(lane, [&](int a) {
             const int c = cur()[a];
@@ -550,7 +551,7 @@ struct Sim {
         }
         return over;
     }
-    __device__ __forceinline__ void terminal(Hdr& h, const KP& P, int lane, double* __restrict__ row) const {
+    __device__ __forceinline__ void terminal(HdrRegs& h, const KP& P, int lane, double* __restrict__ row) const {
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt = __builtin_readcyclecounter();
 #endif
@@ -578,7 +579,7 @@ struct Sim {
     // (worker.py:50-51).  Returns at the next decision point or after terminal().
     // no_grouping: every deciding agent forms ONE group (individual selection, worker.py:159-198 iterates the deciders without
     // get_unique_group); lockstep API only.
-    __device__ __forceinline__ void advance(Hdr& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
+    __device__ __forceinline__ void advance(HdrRegs& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
                                             bool no_grouping = false, bool track = false) const {
         const int A_ = A();
         for (;;) {
@@ -603,7 +604,11 @@ struct Sim {
                     maxarr = av > maxarr ? av : maxarr;
                     allret = allret && (ainfo()[a] & A_RETURNED);
                 });
-                h.now = wave_nanmax(maxarr);                                  // :369
+                // max over the WHOLE arrival lists (:286): the agents' last arrivals, and -- for lists that a masked action made
+                // non-monotone -- the running maximum of the episode kept in the header
+                const double hmax = uni(((const Hdr*)base)->max_arrival);
+                const double lmax = wave_nanmax(maxarr);
+                h.now = lmax > hmax ? lmax : hmax;                            // :369
                 bool allfin = true;
                 for_tasks(lane, [&](int t) { allfin = allfin && (tinfo()[t] & T_FIN); });
                 finished = __all(allret) && __all(allfin);                   // :370
@@ -693,7 +698,7 @@ struct Sim {
     }
 
     // reset + clear_decisions (env/task_env.py:116-140); keeps seed, d, episodes
-    __device__ __forceinline__ void reset_state(Hdr& h, int lane) const {
+    __device__ __forceinline__ void reset_state(HdrRegs& h, int lane) const {
         const int PT_ = PT();
         for_tasks(lane, [&](int t) {
             const uint32_t req = tinfo()[t] & 0xFF;
@@ -720,6 +725,7 @@ struct Sim {
             cur()[a] = -2; ainfo()[a] = 0;
         });
         h.now = 0.0; h.flags = 0; h.cur_group = 0; h.n_groups = 0; h.empty_passes = 0;  // :139-140
+        if (lane == 0) ((Hdr*)base)->max_arrival = 0.0;
     }
 
     // ------------------------------------------------------------------------------ decisions
@@ -728,7 +734,7 @@ struct Sim {
     // the extra SGPR pressure / spills, so it is recomputed with one LDS read + ballot per decision.)
     // lowest: individual selection (DCM_PARAM_NO_GROUPING) -- the deciders act one by one in ascending id, `for agent_id in
     // decision_agents` of worker.py:170, so the next one is simply the lowest pending id (no draw)
-    __device__ __forceinline__ int pick_leader(Hdr& h, int lane, int leader_in, uint64_t k1, AMask& gm, bool lowest = false) const {
+    __device__ __forceinline__ int pick_leader(HdrRegs& h, int lane, int leader_in, uint64_t k1, AMask& gm, bool lowest = false) const {
         gm = group_mask(h.cur_group, lane);
         const int glen = am_count(gm);
         if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return -1; }  // unreachable: groups are never empty
@@ -742,7 +748,7 @@ struct Sim {
 
     // worker.py:57-68: mask + both observation tensors relative to `leader`, straight into the policy's input
     // tensors (fp32 casts of worker.py:62,64).
-    __device__ __forceinline__ void observe(const Hdr& h, int lane, int leader, float* __restrict__ ag,
+    __device__ __forceinline__ void observe(const HdrRegs& h, int lane, int leader, float* __restrict__ ag,
                                             float* __restrict__ tk, uint8_t* __restrict__ mask) const {
         const double now = h.now;
         const double lx = ax()[leader], ly = ay()[leader];
@@ -820,19 +826,21 @@ struct Sim {
 
     // TaskEnv.step (env/task_env.py:326-342) + agent_step (:300-324) for leader + followers, then
     // task_update / agent_update (worker.py:74-76) and the move to the next decision point.
-    __device__ __forceinline__ void apply_and_advance(Hdr& h, const KP& P, int lane, int leader, const AMask& gm0,
+    __device__ __forceinline__ void apply_and_advance(HdrRegs& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
                                                       RouteLog log = RouteLog{nullptr, nullptr, nullptr, 0}, int log_row = 0,
-                                                      bool no_grouping = false, bool check_mask = false,
+                                                      bool no_grouping = false, int host_actions = 0,
                                                       bool incremental = false, bool track = false) const {
+        // host_actions: 0 = the action comes from the device's own valid-action policy (persistent kernel); 1 = from the host
+        // (lockstep API): ANY action in [0, T] is simulated as TaskEnv.step would (env/task_env.py:326-342 has no mask check) --
+        // on a masked task (feasible, or status <= 0 incl. the stale status of quirk Q3, :192-200) vacancy <= 0 sends the
+        // leader alone (:330-336), the task may then list more members than it requires, and an agent released before it
+        // arrives makes its arrival list non-monotone, which is why the header keeps the episode's running maximum; 2 = from
+        // the host with DCM_PARAM_STRICT_MASK: such an action freezes the env instead (DCM_FLAG_BAD_ACTION).
         const int A_ = A(), T_ = T();
         if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
-        if (check_mask && action > 0) {
-            // host-supplied action on a masked task (feasible, or status <= 0 incl. the stale status of quirk Q3;
-            // env/task_env.py:192-200): the policy contract gives such actions probability 0 (attention.py:74-76), and a
-            // surplus member could be released before it arrives, which the compact state (arrival_time[-1] only) does
-            // not represent -- refuse loudly instead of diverging from the reference.
+        if (host_actions == 2 && action > 0) {
             const uint32_t ik = uni(tinfo()[action - 1]);
             if ((ik & T_FEAS) || (int)(int8_t)((ik >> 8) & 0xFF) <= 0) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         }
@@ -911,6 +919,14 @@ struct Sim {
                     log.len[o] = c + 1;
                 }
             }
+        }
+        if (host_actions) {
+            // running maximum of every arrival appended in this episode (see Hdr::max_arrival)
+            double m = __builtin_nan("");
+#pragma unroll
+            for (int i = 0; i < NAW; i++) m = nanmax2(m, ((mm.w[i] >> lane) & 1ull) ? arrv[i] : __builtin_nan(""));
+            const double wm = wave_nanmax(m);
+            if (lane == 0) { Hdr* q = (Hdr*)base; if (wm > q->max_arrival) q->max_arrival = wm; }
         }
         if (action > 0) {
             // :321-322 members.append unless already listed; a re-joining agent keeps its slot but
@@ -1009,6 +1025,7 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, i
         Hdr* h = (Hdr*)rec;
         h->depot_x = depot[2 * (size_t)e]; h->depot_y = depot[2 * (size_t)e + 1];
         h->flags = DCM_FLAG_DONE | (bad ? DCM_FLAG_BAD_INSTANCE : 0u); h->episodes = 0; h->d = 0; h->seed = 0;
+        h->groups = 0; h->reserved = 0; h->max_arrival = 0.0;
     }
 }
 
@@ -1027,7 +1044,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP
     WSYNC();
     S.set_ablog(ablog, e, S.BA(A), S.BT(T), lane);
     S.set_retlog(nullptr, 0, e, lane);
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     h.seed = seeds[e]; h.d = 0;
     if (lane == 0) ((Hdr*)smem)->episodes = 0;
     const bool bad_instance = h.flags & DCM_FLAG_BAD_INSTANCE;                // set by dcm_load_instances, survives resets
@@ -1055,7 +1072,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     S.load_record(rec, lane);
     WSYNC();
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
     float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
@@ -1104,7 +1121,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) *S.dirty() = 0;
     WSYNC();
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     PHK_MARK(0);                                   // record HBM -> LDS (issue + wait)
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
     if (was_active) {
@@ -1116,7 +1133,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, true, false, true);
+                                log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true);
             PHK_MARK(2);                           // apply + updates + advance (+ terminal)
             PHK_INNER();
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
@@ -1210,7 +1227,13 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
                                                         const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
                                                         unsigned char* gscr, double* retlog, int retcap) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    // XCD-aware env placement.  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: XCD k gets a CONTIGUOUS
+    // block of envs, so that the observation rows it rewrites at every decision form one dense region of its L2 instead of
+    // every eighth 480 / 1020-byte row.  With the plain e = blockIdx.x map the strided rows alias in the L2 sets and ~10 % of
+    // the per-decision stores were evicted to HBM: 243 MB per 4096-env launch, against 55 MB with this map -- the compulsory
+    // record in / out + last observation (profiles/r03_xcd_map).
+    const int nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7, x_ = blockIdx.x & 7, i_ = blockIdx.x >> 3;
+    const int e = x_ * q_ + (x_ < r_ ? x_ : r_) + i_, lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
@@ -1224,7 +1247,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
     WSYNC();
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
     float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
@@ -1261,7 +1284,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
             PH_MARK(2);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, false, true);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, 0, true);
             gd += GAMMA;
             left--;
         }
@@ -1271,6 +1294,14 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     const int64_t steps = (int64_t)(left0 - left);
     if (lane == 0 && steps_out) steps_out[e] = steps;
     h.d = d0 + (uint64_t)steps;   // every decision of this kernel is valid, so apply_and_advance counted exactly `steps`
+    {   // Hdr::max_arrival: this kernel only takes valid actions, under which every arrival list is monotone, so the maximum of
+        // the agents' last arrivals IS the running maximum of the episode so far -- folded in once per launch for a later
+        // dcm_step on the same episode
+        double m = 0.0;
+        S.for_agents(lane, [&](int a) { const double av = (S.cur()[a] != -2) ? S.arr()[a] : 0.0; m = av > m ? av : m; });
+        const double wm = wave_nanmax(m);
+        if (lane == 0) { Hdr* q = (Hdr*)smem; if (wm > q->max_arrival) q->max_arrival = wm; }
+    }
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
@@ -1302,7 +1333,7 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
     for (int t = lane; t < T; t += WAVE) {                                  // rows t >= T_e of a ragged batch read as 0
         const size_t o = (size_t)e * T + t;
@@ -1333,7 +1364,7 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int P
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
     S.set_ablog(ablog, e, A, T, lane);
     WSYNC();
-    Hdr h = load_hdr(smem);
+    HdrRegs h = load_hdr(smem);
     if (sum_wait) S.compute_waits(h.now, P.mwt, lane);
     for (int a = lane; a < A; a += WAVE) {                                  // rows a >= A_e of a ragged batch: 0 / NaN timer
         const size_t o = (size_t)e * A + a;
@@ -1478,6 +1509,8 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     // per-function, per-device attribute shared by every handle of the process, so it only ever grows: a later, smaller
     // env must not lower it under an earlier handle's launches.
     static int lds_limit[64] = {0};
+    static std::mutex lds_mutex;                 // handles are created from several host threads (one actor thread per GPU)
+    std::lock_guard<std::mutex> lds_guard(lds_mutex);
     const int dev_slot = params->device & 63;
     int lds = (int)h->L.lds_rec();
     if (h->L.lds_bytes() <= 10240) lds = (int)h->L.lds_bytes();           // persistent kernel of the small layouts: scratch in LDS

@@ -337,10 +337,14 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
                 // agent_step :300-324
                 const double tx_ = action ? uni(R.tx()[action - 1]) : depot_x, ty_ = action ? uni(R.ty()[action - 1]) : depot_y;
+                // (distance, sqrt and division on all lanes -- broadcast LDS reads, wave-uniform values -- and only the stores on
+                //  lane 0: gfx950 runs fp64 VALU instructions with fewer than 16 active lanes 4x slower, profiles/r03_calib)
+                const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
+                const double arrival = now + over_velocity(d);                      // :315,:318
+                const double tdist_new = R.tdist()[a] + d;                          // :317
+                WSYNC();
                 if (lane == 0) {
-                    const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
-                    const double arrival = now + over_velocity(d);                  // :315,:318
-                    R.tdist()[a] += d;                                       // :317
+                    R.tdist()[a] = tdist_new;
                     R.arr()[a] = arrival;
                     // a member released by its task finishing before it arrived re-decides early, so the list is
                     // not monotone in replays with surplus visitors; :286 takes the max over the whole list

@@ -15,7 +15,14 @@ episodes most envs have finished.  With buckets = (1.0, 0.5, 0.25, ...) one grap
 check the host picks the smallest bucket that holds the envs still active, and that graph runs the policy only on those
 rows (gathered by a static index buffer: the active envs first, finished ones as filler) and scatters the actions back.
 """
+import threading
+
 import torch
+
+# Graph capture is a process-wide affair on HIP: one capture at a time.  (Actors on worker threads -- ray_compat.init(
+# concurrent=True) -- draw a new batch shape every training round and re-capture while the others replay; captures run in
+# capture_error_mode="thread_local", so the other threads' launches / allocations do not invalidate them.)
+CAPTURE_LOCK = threading.RLock()
 
 
 class GraphedRollout:
@@ -30,7 +37,10 @@ class GraphedRollout:
         self.action = torch.zeros((B,), dtype=torch.int32, device=dev)
         self._warmup = warmup
         self._epoch = None
-        self.capacity = int(capacity) if capacity is not None else 6 * (A + T) + 64
+        # whole check windows: run() advances `check_every` replays at a time, so the record must hold the window in which the
+        # last episode ends (a capacity that is not a multiple used to raise "raise capacity" although nothing overflowed)
+        cap = int(capacity) if capacity is not None else 6 * (A + T) + 64
+        self.capacity = -(-cap // self.check_every) * self.check_every
         self.rec = None
         if record:
             S = self.capacity
@@ -83,6 +93,10 @@ class GraphedRollout:
         return self.env.step(self.action)
 
     def capture(self, seeds):
+        with CAPTURE_LOCK:
+            return self._capture(seeds)
+
+    def _capture(self, seeds):
         env = self.env
         self.graphs = {}
         for n in self.sizes:
@@ -95,7 +109,7 @@ class GraphedRollout:
             torch.cuda.current_stream(env.device).wait_stream(s)
             torch.cuda.synchronize(env.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._one_step(obs, n)
             self.graphs[n] = g
         # the captured dcm_step bakes in the handle's kernel arguments (per-env sizes pointer, route-log pointers, shape
@@ -132,8 +146,11 @@ class GraphedRollout:
         n, bucket = 0, env.B
         while True:
             g = self.graphs[bucket]
-            for _ in range(self.check_every):
-                g.replay()
+            # (replays are only enqueued here -- microseconds of host time; they must not interleave with another thread's
+            #  capture: the sampler draws from torch's default CUDA generator, whose graph bookkeeping is per process)
+            with CAPTURE_LOCK:
+                for _ in range(self.check_every):
+                    g.replay()
             n += self.check_every
             self.bucket_steps[bucket] += self.check_every
             # obs tensors are the env's static output buffers; one sync per check

@@ -183,12 +183,16 @@ class Runner:
             devices = [torch.device("cuda", i) for i in range(n)]
         dev = devices[int(metaAgentID) % len(devices)]
         n_envs = _CFG["n_envs"]
+        stride = None
         if _CFG["total_envs"] is not None:
             lo, hi = shard_range(int(_CFG["total_envs"]), int(metaAgentID) % _CFG["num_actors"], _CFG["num_actors"])
             n_envs = hi - lo
+            # unequal shards: every actor strides its jobs by the LARGEST shard, so that job e of one actor and job e + 1 of a
+            # smaller-sharded one never overlap (driver.py:116-118 hands out one episode number per job)
+            stride = -(-int(_CFG["total_envs"]) // _CFG["num_actors"])
         with _lock:
             self._r = BatchedRunner(metaAgentID=metaAgentID, n_envs=n_envs, device=str(dev), net_factory=_CFG["net_factory"],
-                                    base_seed=_CFG["base_seed"], **_CFG["runner_kwargs"])
+                                    base_seed=_CFG["base_seed"], episode_stride=stride, **_CFG["runner_kwargs"])
         self.device = self._r.device
         self.localNetwork, self.localBaseline = self._r.localNetwork, self._r.localBaseline
 

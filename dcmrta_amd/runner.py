@@ -38,7 +38,8 @@ class EnvError(RuntimeError):
 
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
-                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets=None):
+                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets=None, episode_stride=None,
+                 env_offset=0, strict_mask=False):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
@@ -48,6 +49,17 @@ class BatchedRunner:
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
+        # job(episodeNumber) plays the instances / seeds [episodeNumber * episode_stride + env_offset, ... + n_envs): with the
+        # default stride n_envs the blocks of successive jobs are disjoint; runners that share one env budget of unequal shards
+        # (dist.shard_range) use a common stride >= the largest shard (ray_compat) or the whole budget plus their shard offset
+        # (dist_runner), so that no two of them ever play the same instance
+        # strict_mask: freeze (and report, EnvError) an env whose policy picks a masked task instead of simulating the action
+        # the way the reference's TaskEnv.step does
+        self.strict_mask = bool(strict_mask)
+        self.episode_stride = int(episode_stride) if episode_stride is not None else self.B
+        self.env_offset = int(env_offset)
+        if self.episode_stride < self.B:
+            raise ValueError("episode_stride must be >= n_envs")
         self.base_seed = int(base_seed)
         self.max_steps = None if max_steps is None else int(max_steps)
         self.gamma = float(gamma)            # GAMMA, parameters.py:6 (1 in the reference)
@@ -94,8 +106,8 @@ class BatchedRunner:
         key = (A, T, bool(individual_selection), int(n_envs or self.B))
         slot = self._cache.get(key)
         if slot is None:
-            slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection),
-                        graphs={})
+            slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection,
+                                           strict_mask=self.strict_mask), graphs={})
             self._cache[key] = slot
             while len(self._cache) > self._cache_shapes:
                 _, old = self._cache.popitem(last=False)
@@ -227,7 +239,7 @@ class BatchedRunner:
         T = int(tasks_num[1] if isinstance(tasks_num, (tuple, list)) else tasks_num)
         slot = self._slot(A, T)
         env = slot["env"]
-        first = int(episodeNumber) * self.B
+        first = self.first_env(episodeNumber)
         ragged = self._is_range(agents_num) or self._is_range(tasks_num)
         if ragged:
             inst = generate_batch_ranges(range(self.base_seed + first, self.base_seed + first + self.B),
@@ -254,6 +266,10 @@ class BatchedRunner:
         self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps, greedy_steps=g_steps,
                          greedy_rec=grec, truncated=truncated)
         return jobResults, metrics, info
+
+    def first_env(self, episodeNumber):
+        """Index of the first instance / seed job(episodeNumber) plays."""
+        return int(episodeNumber) * self.episode_stride + self.env_offset
 
     keep_greedy_record = False    # tests set it to replay the greedy twin through the oracle
 
@@ -303,22 +319,23 @@ class BatchedRunner:
         tr = tuple(tasks_range) if isinstance(tasks_range, (tuple, list)) else int(tasks_range)
         ss = [seed if seed is not None else 0] if seeds is None else list(seeds)
         out = []
-        slot = self._slot(A, T)
-        env = slot["env"]
         net = self._rollout_net()
         ragged = self._is_range(ar) or self._is_range(tr)
         self._set_padding_hint(net, ragged)
         for i in range(0, len(ss), self.B):
             chunk = ss[i:i + self.B]
-            pad = chunk + [chunk[-1]] * (self.B - len(chunk))
-            inst = generate_batch_ranges(pad, ar, tr)      # same draw order as TaskEnv(ar, tr, seed=s), sizes first
+            # a batch of exactly the seeds asked for (its env handle and graphs are cached per size like any other shape):
+            # driver.py:245-250 asks for ONE seed per call, and padding that to n_envs copies cost a full-batch rollout each
+            slot = self._slot(A, T, n_envs=len(chunk))
+            env = slot["env"]
+            inst = generate_batch_ranges(chunk, ar, tr)    # same draw order as TaskEnv(ar, tr, seed=s), sizes first
             if not ragged:
                 inst.pop("n_agents"); inst.pop("n_tasks")  # uniform batch: shape-specialised kernels
             env.load_instances(**inst)
-            cs = np.array([env_seeds(self.base_seed, int(s), 1)[0] for s in pad], dtype=np.uint64)
+            cs = np.array([env_seeds(self.base_seed, int(s), 1)[0] for s in chunk], dtype=np.uint64)
             summary, _, _ = self.rollout(net, slot, cs, "greedy", record=False)
             self._check_flags(env, "testing")
-            out.extend(summary[:len(chunk), 0].cpu().numpy().tolist())
+            out.extend(summary[:, 0].cpu().numpy().tolist())
         return out[0] if seeds is None else np.array(out)
 
     def close(self):

@@ -55,7 +55,7 @@ typedef enum {
 #define DCM_FLAG_DONE 1u       /* episode over (terminal box of worker.py:87) */
 #define DCM_FLAG_FINISHED 2u   /* env.finished is True (env/task_env.py:366-373) */
 #define DCM_FLAG_TRUNCATED 4u  /* zero-decider guard fired (the reference would spin) */
-#define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T], or a task the mask forbids (feasible / status <= 0) */
+#define DCM_FLAG_BAD_ACTION 8u /* action outside [0, T]; with DCM_PARAM_STRICT_MASK also a task the mask forbids */
 #define DCM_FLAG_OVERFLOW 16u  /* a task would exceed DCM_MAX_MEMBERS members / injected follower count too large */
 #define DCM_FLAG_BAD_LEADER 32u /* injected leader/follower not in the current group */
 #define DCM_FLAG_WAIT_ORDER 128u /* informational, does not freeze the env: a per-(agent, task) abandonment counter saturated \
@@ -79,6 +79,14 @@ typedef enum {
  * batch stays full instead of waiting for its longest episode.  Envs frozen by an error flag are not restarted, nor envs
  * that have finished dcm_params.auto_reset_episodes episodes (when that is non-zero). */
 #define DCM_PARAM_AUTO_RESET 2u
+/* dcm_params.flags: refuse host-supplied actions on masked tasks.  By default dcm_step simulates ANY action in [0, T] the way
+ * TaskEnv.step does (env/task_env.py:326-342 never looks at the mask; worker.py:140's argmax can return a masked index): on a
+ * task that is feasible or has status <= 0 the leader goes alone, the task may list more agents than it requires, and time
+ * can even step backwards when an agent joins a task that is already over -- all of it restated.  The one limit is the
+ * member-slot capacity: a task that would list more than DCM_MAX_MEMBERS agents freezes the env with DCM_FLAG_OVERFLOW.  With
+ * this flag such an action freezes the env with DCM_FLAG_BAD_ACTION instead (the policy contract gives masked actions
+ * probability 0, attention.py:74-76: a runner can use it to catch a policy that does not). */
+#define DCM_PARAM_STRICT_MASK 4u
 
 typedef struct {
     int32_t n_envs;             /* B */

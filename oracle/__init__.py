@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-POLICY_RANDOM, POLICY_INJECTED, POLICY_FIRST, POLICY_NEAREST = 0, 1, 2, 3
+POLICY_RANDOM, POLICY_INJECTED, POLICY_FIRST, POLICY_NEAREST, POLICY_ANY = 0, 1, 2, 3, 4
 METRIC_NAMES = ("success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency")
 
 
@@ -69,6 +69,8 @@ def lib():
         L.orc_rollout.restype = i64
         L.orc_rollout.argtypes = [vp, u64, u64, C.c_int, i64] + [vp] * 12
         L.orc_summary_get.argtypes = [vp, C.POINTER(_Summary)]
+        L.orc_max_members_seen.restype = C.c_int
+        L.orc_max_members_seen.argtypes = [vp]
         L.orc_final_tasks.argtypes = [vp] * 8
         L.orc_final_agents.argtypes = [vp] * 5
         L.orc_get_route.restype = C.c_int
@@ -221,7 +223,8 @@ class OracleEnv:
         lib().orc_final_agents(self._h, _p(aw), _p(td), _p(ret), _p(rl))
         return dict(reward=s.reward, makespan=s.makespan, metrics=np.array(list(s.metrics)), truncated=int(s.truncated),
                     finished=fin, feasible=fea, time_start=ts, time_finish=tf, task_wait=tw, n_members=nm,
-                    n_abandoned=na, agent_wait=aw, travel_dist=td, returned=ret, route_len=rl)
+                    n_abandoned=na, agent_wait=aw, travel_dist=td, returned=ret, route_len=rl,
+                    max_members_seen=int(lib().orc_max_members_seen(self._h)))
 
     def route(self, agent, cap=4096):
         """(route, arrival_time) lists of the agent (env/task_env.py:95-96)."""

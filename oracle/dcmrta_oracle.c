@@ -51,6 +51,7 @@ struct orc_env {
      * replayed -- a literal substitution of those four constants, pinned by tests/golden/make_golden_schedule.py */
     int vis_initial, vis_batch, vis_period, vis_cap;
     int truncated;   /* guard flag, not in the reference (SURVEY §5 hazard) */
+    int max_members_seen; /* test aid: longest task['members'] list of the episode (the HIP env holds 5 per task in RL mode) */
     int type_error;  /* the reference would have raised TypeError (:220) */
     double depot[2];
     ivec depot_members; /* :112 */
@@ -158,7 +159,7 @@ void orc_clear_decisions(orc_env *e) {
         e->preset[a].n = 0; e->preset_head[a] = 0; e->preset_none[a] = 1;
     }
     e->depot_members.n = 0;
-    e->now = 0.0; e->finished = 0; e->truncated = 0; e->type_error = 0;
+    e->now = 0.0; e->finished = 0; e->truncated = 0; e->type_error = 0; e->max_members_seen = 0;
     e->reactive = 0; e->visible_length = 0;
 }
 
@@ -359,7 +360,9 @@ void orc_agent_step(orc_env *e, int agent, int action) {
     dv_push(&e->arrival[agent], e->now + travel_time);                      /* :318 */
     e->ax[agent] = tx; e->ay[agent] = ty;                                   /* :320 */
     if (iv_index(members, agent) < 0) iv_push(members, agent);              /* :321-322 */
+    if (task_id != -1 && members->n > e->max_members_seen) e->max_members_seen = members->n;
 }
+int orc_max_members_seen(orc_env *e) { return e->max_members_seen; }
 
 /* env/task_env.py:192-200 + depot bit worker.py:57-61 (1 = forbidden) */
 void orc_mask(orc_env *e, uint8_t *mask) {
@@ -509,6 +512,16 @@ static int policy_pick(orc_env *e, int policy, const uint8_t *mask, int leader, 
         int nv = 0;
         for (int k = 0; k < T1; k++) nv += !mask[k];
         int idx = orc_below(orc_draw(seed_e, d, 1), nv);
+        for (int k = 0; k < T1; k++) if (!mask[k]) { if (idx == 0) return k; idx--; }
+    } else if (policy == ORC_POLICY_ANY) {
+        /* a policy that does not respect the mask (worker.py:140's argmax can return a masked index; TaskEnv.step has no
+         * check, env/task_env.py:326-342): 1 draw in 16 the depot whatever the mask says, 1 in 4 ANY task, else a valid action */
+        uint32_t r = (uint32_t)orc_draw(seed_e, d, 1);
+        if (r % 16u == 1u) return 0;
+        if (r % 4u == 0u) return 1 + (int)((r >> 4) % (uint32_t)e->T);
+        int nv = 0;
+        for (int k = 0; k < T1; k++) nv += !mask[k];
+        int idx = orc_below(r, nv);
         for (int k = 0; k < T1; k++) if (!mask[k]) { if (idx == 0) return k; idx--; }
     } else if (policy == ORC_POLICY_FIRST) {
         for (int k = 0; k < T1; k++) if (!mask[k]) return k;

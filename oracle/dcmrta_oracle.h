@@ -25,7 +25,7 @@ extern "C" {
 typedef struct orc_env orc_env;
 
 /* policies understood by orc_rollout */
-enum { ORC_POLICY_RANDOM = 0, ORC_POLICY_INJECTED = 1, ORC_POLICY_FIRST = 2, ORC_POLICY_NEAREST = 3 };
+enum { ORC_POLICY_RANDOM = 0, ORC_POLICY_INJECTED = 1, ORC_POLICY_FIRST = 2, ORC_POLICY_NEAREST = 3, ORC_POLICY_ANY = 4 /* ignores the mask */ };
 
 orc_env *orc_create(int A, int T);
 void orc_destroy(orc_env *e);
@@ -76,6 +76,7 @@ typedef struct {
     int32_t n_finished;
 } orc_summary;
 void orc_summary_get(orc_env *e, orc_summary *s);
+int orc_max_members_seen(orc_env *e); /* longest task['members'] list since clear_decisions (test aid) */
 void orc_final_tasks(orc_env *e, uint8_t *finished, uint8_t *feasible, double *time_start, double *time_finish,
                      double *task_wait, int32_t *n_members, int32_t *n_abandoned);
 void orc_final_agents(orc_env *e, double *agent_wait, double *travel_dist, uint8_t *returned, int32_t *route_len);

@@ -9,11 +9,11 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _mk(B, A, T, dev, seed=0):
+def _mk(B, A, T, dev, seed=0, **kw):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
     inst = generate_batch(B, A, T, base_seed=seed)
-    return BatchedTaskEnv(B, A, T, device=dev).load_instances(**inst), inst
+    return BatchedTaskEnv(B, A, T, device=dev, **kw).load_instances(**inst), inst
 
 
 def _oracle_random(oracle_lib, inst, seeds, A, T, b, record):
@@ -98,11 +98,12 @@ def test_error_flags_freeze_only_the_offending_env(gpu_device):
     assert nan_rows.all()   # nobody finished an episode yet -> summary rows are NaN
 
 
-def test_masked_task_action_is_refused(gpu_device):
-    """A host-supplied action on a task the mask forbids (worker.py:57-61) sets BAD_ACTION and freezes that env only."""
+def test_masked_task_action_is_refused_in_strict_mode(gpu_device):
+    """DCM_PARAM_STRICT_MASK: a host-supplied action on a task the mask forbids (worker.py:57-61) sets BAD_ACTION and freezes
+    that env only.  (Without the flag the action is simulated like TaskEnv.step does: test_masked_actions_are_simulated.)"""
     from dcmrta_amd import _lib
     from dcmrta_amd.choice import env_seeds
-    env, _ = _mk(3, 6, 9, gpu_device)
+    env, _ = _mk(3, 6, 9, gpu_device, strict_mask=True)
     obs = env.reset(env_seeds(5, 0, 3))
     one = torch.ones(3, dtype=torch.int32, device=gpu_device)
     obs = env.step(one)                                  # task 0 gets exactly its requirement -> status 0 -> masked
@@ -424,3 +425,66 @@ def test_requirements_are_validated_on_the_device(gpu_device):
     env.load_instances(**inst)
     env.reset(env_seeds(1, 0, B), observe=False)
     assert not (env.status()["flags"].cpu().numpy() & _lib.FLAG_BAD_INSTANCE).any()
+
+
+def _anymask_action(mask_row, seed_e, d, T):
+    """Host mirror of ORC_POLICY_ANY / tests/golden/make_golden_masked.py: a policy that does not respect the mask."""
+    from dcmrta_amd.choice import below, draw
+    r = draw(seed_e, d, 1)
+    if r % 16 == 1:
+        return 0
+    if r % 4 == 0:
+        return 1 + (r >> 4) % T
+    valid = np.flatnonzero(mask_row == 0)
+    return int(valid[below(r, len(valid))])
+
+
+def test_masked_actions_are_simulated(gpu_device, oracle_lib, golden_dir):
+    """TaskEnv.step has no mask check (env/task_env.py:326-342): an action on a feasible / full / stale-status task sends the
+    leader alone, the task lists a surplus member, an agent that joins a task that is already over is released in the past
+    and the event time steps backwards.  dcm_step restates all of that; the one limit is the 5 member slots per task: the
+    episode freezes with DCM_FLAG_OVERFLOW at exactly the decision whose agent_step would make a sixth member.
+    (The reference-generated traces trace_*_anymask_* run through test_gpu_parity's golden tests like every other trace.)"""
+    import glob
+    import os
+    from dcmrta_amd import _lib
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    # (1) a batch of random instances, mask-ignoring policy on the host, every env against the oracle
+    B, A, T = 64, 12, 25
+    inst = generate_batch(B, A, T, base_seed=400)
+    seeds = env_seeds(13, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    got = H.run_lockstep(env, seeds, lambda b, i, m, l: _anymask_action(m, int(seeds[b]), i, T))
+    fin = H.gpu_final(env)
+    n_exact = n_over = masked = backwards = 0
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_ANY, cap_steps=20000)
+        overflowed = bool(fin[b]["flags"] & _lib.FLAG_OVERFLOW)
+        assert overflowed == (ref["max_members_seen"] > 5), b            # the freeze is the slot limit, nothing else
+        n = got[b]["n_steps"]
+        for k in ("leader", "action", "now", "mask", "agents_obs", "tasks_obs"):   # identical up to the freeze / the end
+            assert np.array_equal(got[b][k], ref[k][:n]), (b, k)
+        if overflowed:
+            n_over += 1
+            continue
+        assert n == ref["n_steps"] and not fin[b]["flags"] & _lib.FLAG_BAD_ACTION
+        H.assert_final_matches(fin[b], ref, f"env{b}")
+        n_exact += 1
+        masked += int(sum(ref["mask"][i][a] for i, a in enumerate(ref["action"])))
+        backwards += int((np.diff(ref["now"]) < 0).sum())
+    assert n_exact >= 20 and masked > 100 and backwards > 5, (n_exact, n_over, masked, backwards)
+    # (2) the reference's own episodes that run into the slot limit: equal up to that decision, frozen there
+    for p in sorted(glob.glob(os.path.join(golden_dir, "overflow_*.npz"))):
+        tr = H.load_trace(p)
+        A2, T2 = int(tr["A"]), int(tr["T"])
+        e2 = BatchedTaskEnv(1, A2, T2, device=gpu_device).load_instances(tr["depot"][None], tr["task_xy"][None], tr["req"][None],
+                                                                          tr["dur"][None])
+        g = H.run_lockstep(e2, np.array([int(tr["seed_e"])], np.uint64), lambda b, i, m, l: int(tr["action"][i]))[0]
+        stop = int(tr["overflow_step"])
+        assert g["n_steps"] == stop + 1                                     # the overflowing decision is the last one taken
+        for k in ("leader", "now", "mask", "agents_obs", "tasks_obs"):
+            assert np.array_equal(g[k], tr[k][:stop + 1]), (p, k)
+        assert int(e2.status()["flags"].cpu().numpy()[0]) & _lib.FLAG_OVERFLOW

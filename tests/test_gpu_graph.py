@@ -94,3 +94,40 @@ def test_record_capacity_is_enforced(gpu_device):
     g = GraphedRollout(env, first_valid, check_every=4, record=True, capacity=8)
     with pytest.raises(RuntimeError, match="capacity"):
         g.run(env_seeds(1, 0, B))
+
+
+def test_attention_policy_graph_loop_at_full_batch(gpu_device, oracle_lib):
+    """BASELINE configs[2] at its real size: GraphedRollout + the attention net (fp32, the reference's arithmetic) + compaction
+    buckets at B = 4096 for one sampled episode per env -- the size at which two ROCm graph hazards were hit (torch.multinomial
+    faulting on replay, concurrent replays hanging).  A 32-env sample of the recorded episodes replays through the
+    oracle; the record's window rounding lets the last episode end in the final partial check window without a false overflow."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.graph_rollout import GraphedRollout
+    from dcmrta_amd.instances import generate_batch
+    from dcmrta_amd.policy import AttentionNet
+    B, A, T = 4096, 20, 50
+    torch.manual_seed(3)
+    net = AttentionNet().to(gpu_device).eval()
+    net.assume_no_padding = True
+    inst = generate_batch(B, A, T, base_seed=0)
+    seeds = env_seeds(0, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+
+    @torch.no_grad()
+    def policy(ob):
+        lp = net(ob.tasks, ob.agents, ob.mask)
+        return torch.argmax(lp - torch.empty_like(lp).exponential_(1.0).log(), dim=1).to(torch.int32)
+    g = GraphedRollout(env, policy, check_every=4, record=True, capacity=250, buckets=(1.0, 0.5, 0.25, 0.125))
+    assert g.capacity == 252                                     # rounded up to whole check windows
+    summary, n = g.run(seeds)
+    flags = env.status()["flags"].cpu().numpy()
+    assert not (flags & 0x138).any() and (flags & 1).all()       # nobody frozen, everybody done
+    assert sum(v for k, v in g.bucket_steps.items() if k < B) > 0
+    dec = env.status()["decisions"]
+    assert int(g.rec["active"][:n].sum()) == int(dec.sum()) and 60 * B < int(dec.sum()) < 200 * B
+    pick = np.linspace(0, B - 1, 32).astype(int)
+    rec = {k: v[:n][:, pick].contiguous() for k, v in g.rec.items()}
+    sub = {k: v[pick] for k, v in inst.items()}
+    _replay_recorded(oracle_lib, rec, summary[pick].cpu().numpy(), sub, seeds[pick], A, T)
+    assert not rec["mask"].gather(2, rec["action"].unsqueeze(2))[rec["active"]].any()     # no sampled action was masked

@@ -351,3 +351,46 @@ def test_rl_test_example_script(gpu_device, tmp_path):
         assert rows[0] == ",success_rate,makespan,time_cost,waiting_time,travel_dist,efficiency" and len(rows) == 51
         vals = np.array([[float(x) for x in l.split(",")[1:]] for l in rows[1:]])
         assert (vals[:, 0] >= 0).all() and (vals[:, 0] <= 1).all() and (vals[:, 1] > 0).all()
+
+
+def test_concurrent_actors_capture_while_others_replay(gpu_device):
+    """ray_compat.init(concurrent=True): one worker thread per actor, here two actors on the one GPU with REAL graph-captured
+    jobs.  Training draws a new batch shape every round (driver.py:114-115), so both threads create env handles (hipMalloc)
+    and capture HIP graphs while the other one allocates, launches and replays -- the failure shape of a process-wide capture
+    mode.  Captures are serialised by graph_rollout.CAPTURE_LOCK and run in capture_error_mode="thread_local"; dcm_create's
+    per-device LDS attribute table is mutex-guarded.  The deterministic (greedy) results must equal a single-threaded runner's;
+    unequal shards of one env budget must not overlap (common episode stride)."""
+    from dcmrta_amd import ray_compat as ray
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import BatchedRunner
+    torch.manual_seed(5)
+    ray.init(total_envs=45, num_actors=2, devices=[torch.device(gpu_device)], concurrent=True, base_seed=21,
+             net_factory=lambda: AttentionNet(6, 5, 32))
+    actors = [ray.RLRunner.remote(i) for i in range(2)]
+    sizes = [a._obj._r.B for a in actors]
+    assert sizes == [23, 22] and all(a._obj._r.episode_stride == 23 for a in actors)
+    w = {k: v.clone() for k, v in ray.get(actors[0].get_weights.remote()).items()}
+    ep = 0
+    for A, T in ((8, 12), (10, 20), (6, 9), (8, 12)):                    # three new shapes (captures), one cached shape
+        jobs = []
+        for a in actors:
+            jobs.append(a.job.remote(w, w, ep, A, T))
+            ep += 1
+        done, rest = ray.wait(jobs, num_returns=2)
+        assert rest == []
+        for (res, metrics, info), n in zip(ray.get(jobs), sizes):
+            agents = torch.stack(res[0])
+            assert agents.shape[1:] == (A, 6) and agents.shape[0] >= n and np.isfinite(metrics["makespan"])
+            assert int((torch.stack(res[4])[:, 0] != 0).sum()) == n          # one terminal reward per episode of the shard
+    # instance blocks: job e of actor i starts at e * 23 -- disjoint although actor 1 only holds 22 envs
+    assert actors[0]._obj._r.first_env(2) == 46 and actors[1]._obj._r.first_env(1) == 23
+    # greedy evaluation (deterministic) on both threads at once == a plain single-threaded runner with the same weights
+    seeds = list(range(40, 52))
+    refs = [a.testing.remote(seed=s) for s in seeds[:6] for a in actors[:1]] + [actors[1].testing.remote(seed=s) for s in seeds[6:]]
+    got = ray.get(refs)
+    ray.shutdown()
+    single = BatchedRunner(n_envs=4, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32), base_seed=21)
+    single.set_weights(w)
+    exp = single.testing(seeds=seeds)
+    single.close()
+    assert np.array_equal(np.array(got), exp)

@@ -13,7 +13,7 @@ import pytest
 
 import helpers as H
 
-POLICY = {"random": 0, "first": 2, "nearest": 3}
+POLICY = {"random": 0, "first": 2, "nearest": 3, "anymask": 4}   # anymask: ignores the mask (make_golden_masked.py)
 ALL_KEYS = ("leader", "action", "nfol", "followers", "now", "mask", "agents_obs", "tasks_obs", "finished", "feasible",
             "time_start", "time_finish", "task_wait", "n_members", "n_abandoned", "agent_wait", "travel_dist",
             "returned", "route_len", "metrics")
@@ -276,3 +276,26 @@ def test_visibility_schedule_validation(oracle_lib):
     for bad in ((-1, 20, 10, 100), (20, 0, 10, 100), (20, 20, 0, 100), (20, 20, 10, 19)):
         with pytest.raises(ValueError):
             o.set_visibility(*bad)
+
+
+def test_mask_ignoring_policy_traces(oracle_lib, golden_dir):
+    """tests/golden/make_golden_masked.py: the reference driven by a policy that picks masked tasks (and the depot while tasks
+    remain) -- TaskEnv.step simulates those (env/task_env.py:326-342).  The full traces trace_*_anymask_* are checked by
+    test_full_trace_bit_exact like every other trace; here: they really contain masked picks and backward time steps, and the
+    episodes in which a task lists more than 5 members (overflow_*: the HIP env stops there) match to the very end as well."""
+    import glob
+    traces = sorted(glob.glob(os.path.join(golden_dir, "trace_*_anymask_*.npz")))
+    assert len(traces) >= 10
+    assert sum(int(np.load(p)["masked_picks"]) for p in traces) > 50
+    assert sum(int(np.load(p)["time_steps_backwards"]) for p in traces) > 5
+    over = sorted(glob.glob(os.path.join(golden_dir, "overflow_*.npz")))
+    assert len(over) >= 3
+    for p in over:
+        tr = H.load_trace(p)
+        A, T = int(tr["A"]), int(tr["T"])
+        e = oracle_lib.OracleEnv(A, T).load(tr["depot"], tr["task_xy"], tr["req"], tr["dur"])
+        out = e.rollout(int(tr["seed_e"]), 0, oracle_lib.POLICY_ANY, cap_steps=4096)
+        assert out["n_steps"] == int(tr["n_steps"]) and out["reward"] == float(tr["reward"])
+        for k in ALL_KEYS:
+            assert np.array_equal(np.asarray(out[k]), tr[k]), (p, k)
+        assert int(tr["n_members"].max()) > 5 or int(tr["overflow_step"]) >= 0
