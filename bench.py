@@ -189,7 +189,9 @@ class SubBatch:
             # routes only over the tasks that can ever become visible under the schedule (the reference's cap hides the rest)
             self.routes, self.route_len = synthetic_route_arrays(self.inst["req"], A, max_task=min(T, visibility[3]))
             self.env.set_visibility(*visibility)
-            self.env.load_route_arrays(self.routes, self.route_len, member_cap=8)
+            # synthetic routes send exactly req[t] <= 5 agents to task t: 6 member slots per task suffice (an overflow would be
+            # flagged, checked after the run), and at 100A/500T they make the env fit three times into a CU's LDS instead of twice
+            self.env.load_route_arrays(self.routes, self.route_len, member_cap=6)
         else:
             self.ring = self.env.enable_return_log(cfg["episodes"])          # every episode's return of a pass
             self.env.reset(self.seeds, observe=False)
@@ -350,8 +352,11 @@ def main():
     launch_ms = [a.elapsed_time(b) for sb in subs for a, b in sb.ev]
     warm_steps = int(sum(int(torch.stack(sb.warm).sum().item()) for sb in subs if sb.warm))
 
-    if not replay:
-        for sb in subs:
+    for sb in subs:
+        if replay:
+            flags = sb.env.execute_routes(True, fields=())["flags"].cpu().numpy()
+            assert (flags & 0x58).sum() == 0, "replay error flags set (bad action / member overflow / TypeError)"
+        else:
             flags = sb.env.status()["flags"].cpu().numpy()
             assert (flags & 0x138).sum() == 0, "env error flags set"
     if ctx.rank != 0:

@@ -153,9 +153,13 @@ struct Sim {
     }
 
     // record HBM -> LDS (base): every load in flight before the first LDS write when the layout is a compile-time constant
-    template <bool NT = true>
+    // ALL = false: the plain chunk-by-chunk loop (4 VGPRs).  The persistent kernel copies its record once per launch of
+    // hundreds of decisions, so the copy's latency is irrelevant there, while the 32 transient VGPRs of the all-in-flight copy
+    // pushed k_rollout_random<64,64,runtime sizes> from 128 to 132 VGPRs = 3 instead of 4 waves per SIMD = two rounds of
+    // workgroups for a 4096-env batch (5.7e8 instead of 8.1e8 steps/s at 21A/51T).
+    template <bool NT = true, bool ALL = true>
     __device__ __forceinline__ void load_record(const unsigned char* rec, int lane) const {
-        if constexpr (CA != 0) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
+        if constexpr (CA != 0 && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
         else copy16_in(base, rec, L().rec_bytes(), lane);
     }
 
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     S.scr = Sim<CA, CT, RS>::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    S.load_record(rec, lane);
+    S.template load_record<true, false>(rec, lane);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch

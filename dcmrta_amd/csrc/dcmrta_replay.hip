@@ -32,21 +32,24 @@ struct RLay {
     __device__ uint32_t phead() const { return 56 * A; }
     __device__ uint32_t plen() const { return 60 * A; }
     __device__ uint32_t amax() const { return 64 * A; }                    // f64[A] max(arrival_time list), :286
-    __device__ uint32_t tb() const { return 72 * A; }
+    __device__ uint32_t nx() const { return 72 * A; }                      // f64[A] x, y of the agent's NEXT preset target
+    __device__ uint32_t ny() const { return 80 * A; }
+    __device__ uint32_t tb() const { return 88 * A; }
     __device__ uint32_t ts() const { return tb(); }
     __device__ uint32_t tf() const { return tb() + 8 * T; }
-    __device__ uint32_t tx() const { return tb() + 16 * T; }
-    __device__ uint32_t ty() const { return tb() + 24 * T; }
-    __device__ uint32_t tdur() const { return tb() + 32 * T; }
-    __device__ uint32_t tw() const { return tb() + 40 * T; }
-    __device__ uint32_t marr() const { return tb() + 48 * T; }             // f64[MR][T]
+    __device__ uint32_t tw() const { return tb() + 8 * T; }                // terminal only: overwrites time_finish once that is out
+    __device__ uint32_t marr() const { return tb() + 16 * T; }             // f64[MR][T]
     __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
     __device__ uint32_t tnab() const { return tinfo() + 4 * T; }           // u32[T]
     __device__ uint32_t mid() const { return tnab() + 4 * T; }             // u8[MR][T]
     __device__ uint32_t ablog() const { return align16(mid() + MR * T); }  // u16[A][AB_CAP] abandonment log
 };
+// The read-only instance arrays (task x, y, duration: 24 T bytes) stay in the HBM record -- a task's duration is read once, when
+// it becomes feasible; the coordinates of an agent's next target are staged per agent when its route is popped -- and the
+// per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 6: 52.6 KB per env = THREE resident waves per
+// CU instead of the two of rounds 1-2 (74 KB with member_cap 8 and everything in LDS); the kernel is latency-bound.
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16(align16((uint32_t)(72 * A + 48 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
+    return align16(align16((uint32_t)(88 * A + 16 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
 }
 
 struct RP {
@@ -70,6 +73,7 @@ struct Rep {
     int A, T, MR;
     unsigned char* b;
     RLay L;
+    const double *gtx, *gty, *gtd;     // task x, y, duration of this env in its HBM record (read-only)
     __device__ double* ax() const { return (double*)(b + L.ax()); }
     __device__ double* ay() const { return (double*)(b + L.ay()); }
     __device__ double* arr() const { return (double*)(b + L.arr()); }
@@ -83,9 +87,8 @@ struct Rep {
     __device__ int32_t* plen() const { return (int32_t*)(b + L.plen()); }
     __device__ double* ts() const { return (double*)(b + L.ts()); }
     __device__ double* tf() const { return (double*)(b + L.tf()); }
-    __device__ double* tx() const { return (double*)(b + L.tx()); }
-    __device__ double* ty() const { return (double*)(b + L.ty()); }
-    __device__ double* tdur() const { return (double*)(b + L.tdur()); }
+    __device__ double* nx() const { return (double*)(b + L.nx()); }
+    __device__ double* ny() const { return (double*)(b + L.ny()); }
     __device__ double* tw() const { return (double*)(b + L.tw()); }
     __device__ double* marr() const { return (double*)(b + L.marr()); }
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
@@ -111,7 +114,7 @@ struct Rep {
                 double mx = marr()[t], mn = mx;
                 for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
                 if (mx - mn <= mwt) {                                        // :255
-                    const double tfin = mx + tdur()[t];
+                    const double tfin = mx + gtd[t];
                     ts()[t] = mx; tf()[t] = tfin; info |= T_FEAS;            // :256-258
                     touched = now >= tfin;   // only a task that is already over changes again at this `now` (finished, :273)
                 } else {
@@ -242,21 +245,18 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     const int e = blockIdx.x, lane = threadIdx.x;
     const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
     const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
-    Rep R{A, T, MR, smem, RLay{A, T, MR}};
+    Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
+          (const double*)(rec + EL.tdur())};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
     // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance
     {
-        const double* gtx = (const double*)(rec + EL.tx());
-        const double* gty = (const double*)(rec + EL.ty());
-        const double* gtd = (const double*)(rec + EL.tdur());
         const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
         for (int t = lane; t < T; t += WAVE) {
-            R.tx()[t] = gtx[t]; R.ty()[t] = gty[t]; R.tdur()[t] = gtd[t];
             const uint32_t req = gti[t] & 0xFF;
             R.tinfo()[t] = req | (req << 8);
-            R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0; R.tw()[t] = 0.0;
+            R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0;
         }
         for (int a = lane; a < A; a += WAVE) {
             R.ax()[a] = depot_x; R.ay()[a] = depot_y; R.arr()[a] = 0.0; R.amax()[a] = 0.0; R.nd()[a] = 0.0; R.tdist()[a] = 0.0;
@@ -279,7 +279,11 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     // load issued at the pop and consumed after the updates so that its latency hides behind task_update/agent_update
     for (int a = lane; a < A; a += WAVE) {
         const int len = R.plen()[a];
-        R.aw()[a] = (len > 0) ? (double)my_routes[(size_t)a * route_cap] : 0.0;
+        const int32_t first = (len > 0) ? my_routes[(size_t)a * route_cap] : 0;
+        R.aw()[a] = (double)first;
+        const bool task = first >= 1 && first <= T;      // (an out-of-range entry is reported when it is executed)
+        R.nx()[a] = task ? R.gtx[first - 1] : depot_x;
+        R.ny()[a] = task ? R.gty[first - 1] : depot_y;
     }
     WSYNC();
     while (!finished_flag && now < P.cutoff) {                               // :565
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                 int action;
                 bool popped = false;
                 int32_t upcoming = 0;
+                double up_x = depot_x, up_y = depot_y;
                 if (len < 0 || head >= len) action = 0;                      // :573-577
                 else {
                     const int nxt = (int)uni(R.aw()[a]);                     // == my_routes[a][head]
@@ -330,13 +335,18 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                         action = nxt; popped = true;                         // :585 pop(0)
                         if (lane == 0) {
                             R.phead()[a] = head + 1;
-                            if (head + 1 < len) upcoming = my_routes[(size_t)a * route_cap + head + 1];
+                            if (head + 1 < len) {
+                                upcoming = my_routes[(size_t)a * route_cap + head + 1];
+                                if (upcoming >= 1 && upcoming <= T) { up_x = R.gtx[upcoming - 1]; up_y = R.gty[upcoming - 1]; }
+                            }
                         }
                     }
                 }
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
                 // agent_step :300-324
-                const double tx_ = action ? uni(R.tx()[action - 1]) : depot_x, ty_ = action ? uni(R.ty()[action - 1]) : depot_y;
+                // target of a popped action = the coordinates staged for this agent (see `upcoming` below); a forced depot visit
+                // (route exhausted / next task not yet visible) leaves them in place for later
+                const double tx_ = action ? uni(R.nx()[a]) : depot_x, ty_ = action ? uni(R.ny()[a]) : depot_y;
                 // (distance, sqrt and division on all lanes -- broadcast LDS reads, wave-uniform values -- and only the stores on
                 //  lane 0: gfx950 runs fp64 VALU instructions with fewer than 16 active lanes 4x slower, profiles/r03_calib)
                 const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                 if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
                 WSYNC();
                 R.task_update(now, mwt, lane, redo ? -1 : (action > 0 ? action - 1 : -2), redo, n_infeas);   // :575/:582/:586
-                if (popped && lane == 0) R.aw()[a] = (double)upcoming;       // before agent_update: its reactive branch reads it
+                if (popped && lane == 0) { R.aw()[a] = (double)upcoming; R.nx()[a] = up_x; R.ny()[a] = up_y; }   // before agent_update: its reactive branch reads aw
                 WSYNC();
                 R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period);  // :576/:583/:587
                 WSYNC();
@@ -397,6 +407,9 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
             finished_flag = __all(allret) && __all(allfin);
         } else finished_flag = false;
     }
+    WSYNC();
+    // time_finish leaves first: its LDS section is reused for the per-task waiting sums
+    if (time_finish) for (int t = lane; t < T; t += WAVE) time_finish[(size_t)e * T + t] = R.tf()[t];
     WSYNC();
     // ---- get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
     for (int t = lane; t < T; t += WAVE) {
@@ -477,7 +490,6 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
         const uint32_t info = R.tinfo()[t];
         if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
         if (time_start) time_start[o] = R.ts()[t];
-        if (time_finish) time_finish[o] = R.tf()[t];
         if (task_wait) task_wait[o] = R.tw()[t];
         if (n_members) n_members[o] = (info >> 16) & 0xFF;
     }

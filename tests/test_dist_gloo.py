@@ -87,3 +87,17 @@ def test_all_gather_returns_world2(oracle_lib, n_total):
         assert total == int(steps.sum())
         assert tmax == float(world)
     assert sorted(r[4] for r in res) == ([(0, 6), (6, 12)] if n_total == 12 else [(0, 7), (7, 13)])
+
+
+def test_gather_checksum_reads_raw_bits():
+    """verify_gather's cross-rank checksum is taken over the values' bit patterns: float32 returns in (-1, 1) (which a
+    value conversion to int64 would all truncate to 0) and float64 values that differ in the last mantissa bit stay distinct."""
+    from dcmrta_amd.dist import _raw_bits
+    a = torch.tensor([0.25, -0.5, 0.75], dtype=torch.float32)
+    b = torch.tensor([0.25, -0.5, 0.7500001], dtype=torch.float32)
+    assert _raw_bits(a).dtype == torch.int64 and not torch.equal(_raw_bits(a), _raw_bits(b)) and int(_raw_bits(a).abs().min()) > 0
+    x = torch.tensor([-100.68334319265496], dtype=torch.float64)
+    y = torch.from_numpy(np.nextafter(x.numpy(), 0.0))
+    assert not torch.equal(_raw_bits(x), _raw_bits(y))
+    with pytest.raises(TypeError):
+        _raw_bits(torch.zeros(2, dtype=torch.uint8))

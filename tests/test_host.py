@@ -8,6 +8,8 @@ import pytest
 
 import helpers as H
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_library_exports_every_declared_symbol():
     from dcmrta_amd import _lib
@@ -203,3 +205,29 @@ def test_make_test_set_example(tmp_path, golden_dir):
         assert np.array_equal(got["req"][i], ref["req"]) and np.array_equal(got["dur"][i], ref["dur"]) and (got["dur"][i] == 5.0).all()
         for name in ("vehicle_param", "task_param", "planner_param", "graph"):
             assert (out / f"env_{i}" / f"{name}.yaml").exists()
+
+
+def test_persistent_kernel_keeps_four_waves_per_simd(tmp_path):
+    """BASELINE configs[1] is 4096 envs = exactly four single-wave workgroups per SIMD (1024 SIMDs): the one-chunk instantiations of
+    the persistent kernel must stay within 128 VGPRs, or a 4096-env batch needs two rounds of workgroups (a 30 % drop that round 3
+    hit when a transient 32-VGPR copy pushed one instantiation to 132).  Checked on the compiler's own resource report."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "dcmrta_amd", "csrc", "dcmrta_env.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S",
+                          "--cuda-device-only", src, "-o", str(tmp_path / "env.s"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    usage = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", out.stderr, re.S):
+        usage[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    seen = 0
+    for name, (vgprs, occ) in usage.items():
+        if "k_rollout_random" in name and any(t in name for t in ("ILi20ELi50ELb0E", "ILi20ELi50ELb1E", "ILi64ELi64ELb1E")):
+            assert vgprs <= 128 and occ >= 4, (name, vgprs, occ)
+            seen += 1
+    assert seen == 3, sorted(usage)
