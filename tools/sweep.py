@@ -25,6 +25,7 @@ AGENT_KEYS = ("travel_dist", "returned", "agent_wait")
 bad, checked, t0 = 0, 0, time.time()
 wait_order = 0
 is_cnt = 0
+masked_cnt = 0
 for it in range(n_shapes):
     A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
     T = int(rng.choice([1, 2, 7, 20, 37, 50, 63, 64, 65, 100, 128, 129, 200, 300]))
@@ -138,4 +139,46 @@ for it in range(n_shapes):
                 bad += 1
                 print("MISMATCH individual-selection", A, T, mwt, base, b, flush=True)
         env.close()
-print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {is_cnt} in individual-selection mode, {time.time() - t0:.0f} s")
+    # a policy that ignores the mask (TaskEnv.step simulates masked actions, env/task_env.py:326-342): lockstep API with the host
+    # mirror of ORC_POLICY_ANY; an env may only freeze (DCM_FLAG_OVERFLOW) when the oracle's longest member list exceeds 5
+    if it % 6 == 1 and A <= 64 and T <= 130 and not ragged:
+        nB = min(B, 12)
+        env = BatchedTaskEnv(nB, A, T, max_waiting_time=mwt, max_time=max_time).load_instances(**{k: v[:nB] for k, v in inst.items()})
+
+        def anymask(b, i, m, l):
+            from dcmrta_amd.choice import below, draw
+            r = draw(int(seeds[b]), i, 1)
+            if r % 16 == 1:
+                return 0
+            if r % 4 == 0:
+                return 1 + (r >> 4) % T
+            valid = np.flatnonzero(m == 0)
+            return int(valid[below(r, len(valid))])
+        try:
+            got = H.run_lockstep(env, seeds[:nB], anymask, max_iters=20000)
+        except RuntimeError:
+            got = None                                     # (time can step backwards: an episode may not end within the cap)
+        if got is not None:
+            fin = H.gpu_final(env)
+            for b in range(nB):
+                o = oracle.OracleEnv(A, T, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+                try:
+                    ref = o.rollout(int(seeds[b]), 0, oracle.POLICY_ANY, cap_steps=20000, record=True)
+                except RuntimeError:
+                    continue
+                g, n = got[b], got[b]["n_steps"]
+                over = bool(fin[b]["flags"] & 16)
+                ok = over == (ref["max_members_seen"] > 5) and all(np.array_equal(g[k], ref[k][:n]) for k in ("leader", "now", "mask", "agents_obs", "tasks_obs"))
+                if ok and not over:
+                    try:
+                        assert n == ref["n_steps"]
+                        H.assert_final_matches(fin[b], ref, "anymask")
+                    except AssertionError:
+                        ok = False
+                checked += 1
+                masked_cnt += 1
+                if not ok:
+                    bad += 1
+                    print("MISMATCH mask-ignoring policy", A, T, mwt, base, b, flush=True)
+        env.close()
+print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {is_cnt} in individual-selection mode, {masked_cnt} under a mask-ignoring policy, {time.time() - t0:.0f} s")
