@@ -149,12 +149,14 @@ def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seco
                 single_thread_rate=n0 / dt0)
 
 
-def lockstep_kernel_probe(A, T, dev, B=65536, n=24):
+def lockstep_kernel_probe(A, T, dev, B=65536, n=40, warm=8):
     """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
     decision: the HBM roofline of this path is quoted on it, at a batch that fills the machine, HIP events around
-    dcm_step only, device-side random policy."""
+    dcm_step only, device-side random policy; `warm` untimed steps first (the GPU has idled through the CPU baseline)."""
     env = BatchedTaskEnv(B, A, T, device=str(dev)).load_instances(**generate_batch(B, A, T, base_seed=0))
     obs = env.reset(env_seeds(0, 0, B))
+    for _ in range(warm):
+        obs = env.step(torch.multinomial((~obs.mask).float(), 1).squeeze(1).int())
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for i in range(n):
         act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()

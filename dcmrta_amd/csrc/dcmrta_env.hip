@@ -1003,6 +1003,18 @@ __device__ __forceinline__ void env_dims(const int32_t* sizes, int e, int A, int
 }
 
 // ---------------------------------------------------------------------------------- kernels
+// XCD-aware env placement of the one-workgroup-per-env kernels.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
+// L2 and its own path to memory): workgroup b runs env  xcd(b) * ceil(B/8) + b/8,  i.e. every XCD owns a CONTIGUOUS block of envs.
+//  * persistent kernel: the observation rows an XCD rewrites at every decision are one dense region of its L2 instead of every
+//    eighth 480 / 1020-byte row, which aliased in the L2 sets and sent ~10 % of the per-decision stores to HBM (243 MB per
+//    4096-env launch; 55 MB = the compulsory traffic with this map, profiles/r03_xcd_map);
+//  * lockstep kernel: with e = blockIdx.x all XCDs stream through the SAME neighbourhood of the state array at any moment; with
+//    contiguous blocks they work in eight separate regions: 147-170 -> 136 us at 65 536 envs (0.80 of the HBM peak).
+__device__ __forceinline__ int env_of_workgroup() {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, int PT, unsigned char* state, const double* depot,
                                                         const double* task_xy, const int32_t* req, const double* dur,
                                                         const int32_t* sizes) {
@@ -1037,7 +1049,7 @@ template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP P, unsigned char* state, const uint64_t* seeds,
                                                double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes,
                                                unsigned char* gscr) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
@@ -1067,7 +1079,7 @@ template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
                                                  const int32_t* leader_in, const int32_t* sizes, uint32_t mode) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};   // (observe never reaches the terminal metrics: no scratch)
@@ -1103,7 +1115,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                                               int32_t* leader_out, uint8_t* active_out, double* summary, RouteLog log,
                                               uint16_t* ablog, uint32_t mode, const int32_t* sizes, unsigned char* gscr,
                                               uint32_t max_episodes, double* retlog, int retcap) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
@@ -1231,13 +1243,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
                                                         const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
                                                         unsigned char* gscr, double* retlog, int retcap) {
-    // XCD-aware env placement.  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: XCD k gets a CONTIGUOUS
-    // block of envs, so that the observation rows it rewrites at every decision form one dense region of its L2 instead of
-    // every eighth 480 / 1020-byte row.  With the plain e = blockIdx.x map the strided rows alias in the L2 sets and ~10 % of
-    // the per-decision stores were evicted to HBM: 243 MB per 4096-env launch, against 55 MB with this map -- the compulsory
-    // record in / out + last observation (profiles/r03_xcd_map).
-    const int nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7, x_ = blockIdx.x & 7, i_ = blockIdx.x >> 3;
-    const int e = x_ * q_ + (x_ < r_ ? x_ : r_) + i_, lane = threadIdx.x;
+    const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
