@@ -10,7 +10,10 @@
  * against (i) the reference-published known answer -- CTAS-D routes replayed through
  * execute_by_route reproduce testSet_20A_50T_CONDET/metrics/metrics.csv:2 -- and
  * (ii) golden step traces produced by importing the reference in the build container
- * (tests/golden/make_golden.py).
+ * (tests/golden/make_golden.py, make_golden_extra.py), incl. (round 3) traces of a policy that
+ * ignores the action mask (make_golden_masked.py: masked picks, surplus members, event times that
+ * step backwards) and route replays of the reference with its four dynamic-arrival literals
+ * substituted (make_golden_schedule.py, for orc_set_visibility).
  *
  * Every function cites the reference file:line it follows.
  */
