@@ -120,7 +120,7 @@ def cpu_baseline(inst, seeds, A, target_core_seconds=12.0):
                 single_thread_rate=rate1)
 
 
-def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seconds=12.0):
+def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seconds=12.0, reactive=True):
     """Config 5: the oracle's execute_by_route (reactive) on the host cores, one env per thread (the ctypes call releases the
     GIL), on a bounded sample of the same instances and routes."""
     import oracle
@@ -134,7 +134,7 @@ def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seco
         for a in range(A):
             if route_len[b, a] >= 0:
                 o.pre_set_route(routes[b, a, :route_len[b, a]], a)
-        return int(o.execute_by_route(True)["route_len"].sum())          # agent_step calls of the episode
+        return int(o.execute_by_route(reactive)["route_len"].sum())      # agent_step calls of the episode
     t0 = time.perf_counter()
     n0 = one(0)
     dt0 = time.perf_counter() - t0
@@ -180,16 +180,16 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=40, warm=8):
 class SubBatch:
     """One contiguous block of the rank's envs: its own handle and (for more than one sub-batch) its own HIP stream."""
 
-    def __init__(self, cfg, first, B, dev, stream, visibility):
+    def __init__(self, cfg, first, B, dev, stream, visibility, reactive=True):
         A, T = cfg["agents"], cfg["tasks"]
-        self.first, self.B, self.stream, self.replay = first, B, stream, cfg["kernel"] == "k_replay"
+        self.first, self.B, self.stream, self.replay, self.reactive = first, B, stream, cfg["kernel"] == "k_replay", reactive
         self.inst = generate_batch(B, A, T, base_seed=0, first=first)
         self.seeds = env_seeds(0, first, B)
         self.env = BatchedTaskEnv(B, A, T, device=str(dev))
         self.env.load_instances(**self.inst)
         if self.replay:
             # routes only over the tasks that can ever become visible under the schedule (the reference's cap hides the rest)
-            self.routes, self.route_len = synthetic_route_arrays(self.inst["req"], A, max_task=min(T, visibility[3]))
+            self.routes, self.route_len = synthetic_route_arrays(self.inst["req"], A, max_task=min(T, visibility[3]) if reactive else None)
             self.env.set_visibility(*visibility)
             # synthetic routes send exactly req[t] <= 5 agents to task t: 6 member slots per task suffice (an overflow would be
             # flagged, checked after the run), and at 100A/500T they make the env fit three times into a CU's LDS instead of twice
@@ -202,7 +202,7 @@ class SubBatch:
     def run(self, episodes, write_obs):
         """One pass of this sub-batch; returns (steps int64[B], returns f64[B, episodes])."""
         if self.replay:
-            out = self.env.execute_routes(True, fields=())
+            out = self.env.execute_routes(self.reactive, fields=())
             return out["steps"], out["summary"][:, :1]
         return self.env.rollout_random(episodes=episodes, write_obs=write_obs), self.ring
 
@@ -220,7 +220,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="sub-batches (HIP streams) per GPU; 0 = calibrate 4 / 2 / 1 before the warm-up and keep the fastest")
     ap.add_argument("--visibility", default=None,
-                    help="config 5: initial,batch,period,cap of the dynamic-arrival schedule (default: the reference's 20,20,10,100)")
+                    help="config 5: initial,batch,period,cap of the dynamic-arrival schedule (default: the reference's 20,20,10,100); "
+                         "'static' = no dynamic arrivals at all (execute_by_route with reactive_planning False, every task routed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
@@ -231,7 +232,8 @@ def main():
             cfg[k] = getattr(args, k)
     A, T, EP = cfg["agents"], cfg["tasks"], cfg["episodes"]
     replay = cfg["kernel"] == "k_replay"
-    visibility = tuple(int(x) for x in args.visibility.split(",")) if args.visibility else REFERENCE_VISIBILITY
+    static_replay = args.visibility == "static"
+    visibility = (REFERENCE_VISIBILITY if (static_replay or not args.visibility) else tuple(int(x) for x in args.visibility.split(",")))
     if replay:
         EP = 1
 
@@ -254,7 +256,8 @@ def main():
         out = []
         for k in range(S):
             lo, hi = shard_range(B, k, S)
-            out.append(SubBatch(cfg, first + lo, hi - lo, dev, main_stream if S == 1 else side_streams[k], visibility))
+            out.append(SubBatch(cfg, first + lo, hi - lo, dev, main_stream if S == 1 else side_streams[k], visibility,
+                                reactive=not static_replay))
         torch.cuda.synchronize(dev)
         return out
 
@@ -356,7 +359,7 @@ def main():
 
     for sb in subs:
         if replay:
-            flags = sb.env.execute_routes(True, fields=())["flags"].cpu().numpy()
+            flags = sb.env.execute_routes(sb.reactive, fields=())["flags"].cpu().numpy()
             assert (flags & 0x58).sum() == 0, "replay error flags set (bad action / member overflow / TypeError)"
         else:
             flags = sb.env.status()["flags"].cpu().numpy()
@@ -370,6 +373,8 @@ def main():
     unit = "agent_step" if replay else "decision"
     Wb = algorithmic_bytes_per_step(A, T)
     vis_tag = "" if (not replay or visibility == REFERENCE_VISIBILITY) else ":vis" + "-".join(str(v) for v in visibility)
+    if static_replay:
+        vis_tag = ":static"
     c = load_counters(f"{cfg['kernel']}:{A}A{T}T{vis_tag}")      # per-step PMC averages measured by tools/profile.sh
     build = _lib.build_id()
     roof = {"kernel": cfg["kernel"], "avg_launch_ms": float(np.mean(launch_ms)), "launches_per_step": S,
@@ -400,6 +405,8 @@ def main():
     what = (f"route replay with dynamic task arrivals (visibility schedule initial,batch,period,cap = {visibility}"
             + (", the reference's constants" if visibility == REFERENCE_VISIBILITY else ", GENERALISED: not the reference's constants")
             + "), synthetic preset routes") if replay else "random-policy rollout"
+    if static_replay:
+        what = "route replay WITHOUT dynamic arrivals (reactive_planning False: not BASELINE configs[4]), synthetic preset routes over all tasks"
     out = {
         "metric": "env_steps_per_sec", "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": ctx.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": cfg["scaling"],
@@ -413,7 +420,7 @@ def main():
                    "envs_per_gpu": B, "envs_total": n_total, "agents": A, "tasks": T, "episodes_per_step": EP,
                    "decisions_per_step_per_gpu": dec_per_step, "decisions_in_warmup_per_gpu": warm_steps, "streams_per_gpu": S,
                    "stream_calibration_ms_per_pass": ({str(k): v * 1e3 for k, v in calibration.items()} if calibration else None),
-                   "visibility": list(visibility) if replay else None,
+                   "visibility": ("static" if static_replay else list(visibility)) if replay else None,
                    "sharding": f"env batch x{ctx.world}, no data-path collective"
                                + (f", one async all-gather of the {EP} episode return(s) of every env per pass" if ctx.active else ""),
                    "dist_backend": ctx.backend or None},
@@ -424,7 +431,8 @@ def main():
         inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
         if replay:
             out["cpu_baseline"] = cpu_baseline_replay(inst, np.concatenate([x.routes for x in subs]),
-                                                      np.concatenate([x.route_len for x in subs]), A, visibility)
+                                                      np.concatenate([x.route_len for x in subs]), A, visibility,
+                                                      reactive=not static_replay)
         else:
             out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
     if ctx.world == 1 and not args.no_lockstep_probe and not replay:

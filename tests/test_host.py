@@ -231,3 +231,44 @@ def test_persistent_kernel_keeps_four_waves_per_simd(tmp_path):
             assert vgprs <= 128 and occ >= 4, (name, vgprs, occ)
             seen += 1
     assert seen == 3, sorted(usage)
+
+
+def test_synthetic_route_arrays_match_the_list_form():
+    """The batch / array form of the benchmark's preset routes (bench.py --config 5) == the per-env list form."""
+    from dcmrta_amd.instances import generate_batch, synthetic_route_arrays, synthetic_routes
+    inst = generate_batch(7, 13, 37, base_seed=3)
+    for max_task in (None, 20, 100):
+        routes, length = synthetic_route_arrays(inst["req"], 13, max_task)
+        assert routes.dtype == np.int32 and length.dtype == np.int32 and routes.shape[:2] == (7, 13)
+        for b in range(7):
+            ref = synthetic_routes(inst["req"][b], 13, max_task)
+            for a in range(13):
+                assert list(routes[b, a, :length[b, a]]) == ref[a] and (routes[b, a, length[b, a]:] == 0).all()
+                assert ref[a][-1] == 0                                   # every route ends at the depot
+
+
+def test_issue_roofline_pricing():
+    """roofline.issue_roofline: fp64-class instructions at 4.25 clocks, the rest at 2.35 (frac), everything at 4.25 (frac_hi), the
+    scalar unit at 1.07 clocks per instruction per CU; a counter set of another kernel build is reported stale."""
+    from dcmrta_amd import roofline as R
+    c = {"SQ_INSTS_VALU_per_decision": 100.0, "SQ_INSTS_SALU_per_decision": 50.0, "SQ_INSTS_VALU_ADD_F64_per_decision": 10.0,
+         "SQ_INSTS_VALU_MUL_F64_per_decision": 2.0, "SQ_INSTS_VALU_FMA_F64_per_decision": 3.0, "SQ_INSTS_VALU_TRANS_F64_per_decision": 1.0,
+         "SQ_INSTS_VALU_CVT_per_decision": 4.0, "SQ_THREAD_CYCLES_VALU_per_decision": 3200.0, "SQ_ACTIVE_INST_VALU_per_decision": 100.0,
+         "SQ_WAVE_CYCLES_per_decision": 1000.0, "SQ_ACTIVE_INST_ANY_per_decision": 400.0, "SQ_WAIT_ANY_per_decision": 500.0,
+         "SQ_WAIT_INST_ANY_per_decision": 100.0, "build_id": "abc"}
+    r = R.issue_roofline(c, units_per_step=1e6, step_s=1e-3)
+    busy = 4.25 * 20 + 2.35 * 80
+    assert abs(r["frac"] - busy * 1e9 / (1024 * 2.4e9)) < 1e-12 and abs(r["frac_hi"] - 425 * 1e9 / (1024 * 2.4e9)) < 1e-12
+    assert abs(r["salu_issue_frac"] - 50 * 1.07 * 1e9 / (256 * 2.4e9)) < 1e-12 and r["lane_util"] == 0.5
+    assert r["wave_time_split"] == {"executing": 0.4, "parked_on_waitcnt": 0.5, "issue_stalled": 0.1}
+    assert r["frac"] <= r["frac_hi"] and r["pricing"]["class_counters"] is True and r["bound"] == "valu_issue"
+    assert R.staleness(c, "abc") is False and R.staleness(c, "abd") is True and R.staleness({}, "abc") is True
+    del c["SQ_INSTS_VALU_CVT_per_decision"]                            # no class counters: every instruction at the 32-bit rate
+    r2 = R.issue_roofline(c, 1e6, 1e-3)
+    assert r2["pricing"]["class_counters"] is False and abs(r2["frac"] - 235 * 1e9 / (1024 * 2.4e9)) < 1e-12
+    # the committed counter sets all describe ONE kernel build
+    import json
+    allc = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    assert len({v.get("build_id") for v in allc.values()}) == 1 and all(v.get("build_id") for v in allc.values())
+    for key in ("k_rollout_random:20A50T", "k_rollout_random:50A200T", "k_replay:100A500T", "k_step:4096x20A50T", "k_step:65536x20A50T"):
+        assert key in allc, key                                         # every BASELINE config's dominant kernel has a profile

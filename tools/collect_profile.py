@@ -62,7 +62,7 @@ with open(f"{dst}/pmc_{kern}.csv", "w") as f:
     f.write("# passes %d (incl. warm-up), decisions in all passes %d\n" % (passes, decisions))
 per = {f"{k}_per_decision": v / decisions for k, v in tot.items()}
 vis = cfg.get("visibility")
-vis_tag = "" if not vis or list(vis) == [20, 20, 10, 100] else ":vis" + "-".join(str(v) for v in vis)
+vis_tag = ":static" if vis == "static" else ("" if not vis or list(vis) == [20, 20, 10, 100] else ":vis" + "-".join(str(v) for v in vis))
 key = f"{kern}:{cfg['agents']}A{cfg['tasks']}T{vis_tag}"
 entry = dict(per, source=f"profiles/{name}/pmc_{kern}.csv", envs_per_gpu=cfg["envs_per_gpu"], streams=cfg.get("streams_per_gpu", 1),
              decisions_profiled=decisions,
