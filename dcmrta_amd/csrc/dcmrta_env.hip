@@ -86,6 +86,14 @@ struct Sim {
     int pA, pT;           // record layout dims (read by the <0,0> instantiation only)
     unsigned char* base;  // record base (LDS in the env kernels)
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
+    // Exact multi-chunk shapes (50A/200T, 100A/500T): the task coordinates -- read-only instance data that only the task's own
+    // lane and, for the chosen task, the whole wave ever read -- live in two registers per lane chunk (struct XY, owned by the
+    // kernel and handed to observe / apply_and_advance) instead of 16 bytes per task of LDS.  The LDS image of a 50A/200T env
+    // shrinks from 21.7 to 18.5 KB = 8 instead of 7 resident workgroups per CU: config 4 launch 9.63 -> 9.08 ms (-5.8 %),
+    // k_step<50,200> at 16 384 envs -4 %.  (For the one-chunk layouts the same change was measured SLOWER: their kernels are
+    // limited by registers, not LDS.)
+    static constexpr bool IRB = (CT > WAVE) && !RS;
+    struct XY { double x[IRB ? NTC : 1], y[IRB ? NTC : 1]; };
     // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
     // BASELINE batch be resident); every other kernel trades it for more resident workgroups
     static constexpr bool SCR_IN_LDS = (CA != 0 && Lay{CA, CT}.lds_bytes() <= 10240);   // 16 workgroups per CU still fit
@@ -133,21 +141,35 @@ struct Sim {
     __device__ __forceinline__ uint32_t* tnab() const { return (uint32_t*)(base + L().tnab()); }
     __device__ __forceinline__ double* tx() const { return (double*)(base + L().tx()); }
     __device__ __forceinline__ double* ty() const { return (double*)(base + L().ty()); }
-    __device__ __forceinline__ double* tdur() const { return (double*)(base + L().tdur()); }
+    __device__ __forceinline__ double* tdur() const { return (double*)(base + (IRB ? L().tx() : L().tdur())); }   // IRB image: no x / y sections
+    __device__ __forceinline__ uint32_t aux_off() const { return IRB ? L().tx() + 8u * (uint32_t)PT() : L().aux(); }
+    static __host__ __device__ constexpr uint32_t lds_image_bytes(Lay l) { return IRB ? l.tx() + 8u * (uint32_t)l.T + 48u : l.lds_rec(); }
+    // coordinates of task k (wave-uniform k): lane k & 63 of chunk k >> 6 holds them, or the LDS image does
+    __device__ __forceinline__ void task_xy(int k, const XY& xy, double& x, double& y) const {
+        if constexpr (IRB) {
+            const int kc = k >> 6, kl = k & 63;
+            x = 0.; y = 0.;
+#pragma unroll
+            for (int c = 0; c < NTC; c++) if (c == kc) {
+                x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xy.x[c]), kl), __builtin_amdgcn_readlane(__double2loint(xy.x[c]), kl));
+                y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xy.y[c]), kl), __builtin_amdgcn_readlane(__double2loint(xy.y[c]), kl));
+            }
+        } else { x = tx()[k]; y = ty()[k]; }
+    }
     __device__ __forceinline__ double* tw() const { return (double*)(scr + L().s_tw()); }
     __device__ __forceinline__ double* aw() const { return (double*)(scr + L().s_aw()); }
     __device__ __forceinline__ uint16_t* absort() const { return (uint16_t*)(scr + L().s_absort()); }
     __device__ __forceinline__ double* tmx() const { return (double*)(scr + L().s_tmx()); }
     __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(scr + L().s_amask()); }
     // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
-    __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + L().aux()); }
-    __device__ __forceinline__ uint8_t* abcnt() const { return *(uint8_t* const*)(base + L().aux() + 16); }
+    __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + aux_off()); }
+    __device__ __forceinline__ uint8_t* abcnt() const { return *(uint8_t* const*)(base + aux_off() + 16); }
     // (pitch_A / pitch_T = sizes the side tables are laid out for = the batch maximum; equal A() / T() unless the batch is
     //  ragged.  One workgroup per env: gridDim.x is the batch size, the count tables follow the logs of all envs.)
     __device__ __forceinline__ void set_ablog(uint16_t* table, int env_index, int pitch_A, int pitch_T, int lane) const {
         if (lane == 0) {
-            *(uint16_t**)(base + L().aux()) = table + (size_t)env_index * pitch_A * AB_CAP;
-            *(uint8_t**)(base + L().aux() + 16) = (uint8_t*)(table + (size_t)gridDim.x * pitch_A * AB_CAP) +
+            *(uint16_t**)(base + aux_off()) = table + (size_t)env_index * pitch_A * AB_CAP;
+            *(uint8_t**)(base + aux_off() + 16) = (uint8_t*)(table + (size_t)gridDim.x * pitch_A * AB_CAP) +
                                                   (size_t)env_index * abcnt_pitch(pitch_A, pitch_T);
         }
     }
@@ -158,16 +180,31 @@ struct Sim {
     // pushed k_rollout_random<64,64,runtime sizes> from 128 to 132 VGPRs = 3 instead of 4 waves per SIMD = two rounds of
     // workgroups for a 4096-env batch (5.7e8 instead of 8.1e8 steps/s at 21A/51T).
     template <bool NT = true, bool ALL = true>
-    __device__ __forceinline__ void load_record(const unsigned char* rec, int lane) const {
-        if constexpr (CA != 0 && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
+    __device__ __forceinline__ void load_record(const unsigned char* rec, int lane, XY& xy) const {
+        if constexpr (IRB) {
+            constexpr Lay l{CA, CT};
+#pragma unroll
+            for (int c = 0; c < NTC; c++) {
+                const int t = c * WAVE + lane < CT ? c * WAVE + lane : 0;
+                xy.x[c] = ((const double*)(rec + l.tx()))[t];
+                xy.y[c] = ((const double*)(rec + l.ty()))[t];
+            }
+            if constexpr (ALL) {       // mutable part, then the durations right behind it (the x / y sections are skipped)
+                copy16_in_all<l.mut_bytes(), NT>(base, rec, lane);
+                copy16_in_all<align16(8 * CT), NT>(base + l.tx(), rec + l.tdur(), lane);
+            } else {
+                copy16_in(base, rec, l.mut_bytes(), lane);
+                copy16_in(base + l.tx(), rec + l.tdur(), align16(8 * CT), lane);
+            }
+        } else if constexpr (CA != 0 && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
         else copy16_in(base, rec, L().rec_bytes(), lane);
     }
 
     // optional return log (dcm_set_return_log): this env's ring of `cap` episode returns; pointer kept in the LDS image
     __device__ __forceinline__ void set_retlog(double* log, int cap, int env_index, int lane) const {
         if (lane == 0) {
-            *(double**)(base + L().aux() + 32) = log ? log + (size_t)env_index * cap : nullptr;
-            *(int32_t*)(base + L().aux() + 40) = cap;
+            *(double**)(base + aux_off() + 32) = log ? log + (size_t)env_index * cap : nullptr;
+            *(int32_t*)(base + aux_off() + 40) = cap;
         }
     }
 
@@ -223,11 +260,11 @@ struct Sim {
     // of `only`; every other task is at a fixed point of task_update.  inc_state()[0] carries the number of infeasible
     // tasks for np.all(feasible) :279.
     static constexpr bool INC = (CT == 0 || CT > WAVE);
-    __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + L().aux() + 8); }
+    __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + aux_off() + 8); }
     // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..M member-arrival row j,
     // bit 6 member ids, bit 7 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
     static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_IDS = 1u << 6, DIRTY_NAB = 1u << 7, DIRTY_ALL = 0xFFu;
-    __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + L().aux() + 24); }
+    __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + aux_off() + 24); }
     __device__ __forceinline__ void task_update(const HdrRegs& h, const KP& P, int lane, int only = -1, bool track = false) const {
         const double now = h.now, mwt = P.mwt;
         const int T_ = T(), PT_ = PT();
@@ -571,8 +608,8 @@ struct Sim {
         if (lane == 0) {                              // cold header fields stay in the LDS record
             const uint32_t n = ((Hdr*)base)->episodes;
             ((Hdr*)base)->episodes = n + 1;
-            double* ring = *(double* const*)(base + L().aux() + 32);          // dcm_set_return_log
-            if (ring) ring[n % (uint32_t)*(const int32_t*)(base + L().aux() + 40)] = -h.now;   // reward, env/task_env.py:424
+            double* ring = *(double* const*)(base + aux_off() + 32);          // dcm_set_return_log
+            if (ring) ring[n % (uint32_t)*(const int32_t*)(base + aux_off() + 40)] = -h.now;   // reward, env/task_env.py:424
         }
         h.cur_group = 0;
     }
@@ -753,7 +790,7 @@ struct Sim {
     // worker.py:57-68: mask + both observation tensors relative to `leader`, straight into the policy's input
     // tensors (fp32 casts of worker.py:62,64).
     __device__ __forceinline__ void observe(const HdrRegs& h, int lane, int leader, float* __restrict__ ag,
-                                            float* __restrict__ tk, uint8_t* __restrict__ mask) const {
+                                            float* __restrict__ tk, uint8_t* __restrict__ mask, const XY& xy) const {
         const double now = h.now;
         const double lx = ax()[leader], ly = ay()[leader];
         // get_current_agent_status, env/task_env.py:165-180
@@ -784,7 +821,12 @@ struct Sim {
             if (tk) {
                 float* row = tk + 5 * (t + 1);                                // :185-186
                 row[0] = (float)status; row[1] = (float)(info & 0xFF); row[2] = (float)tdur()[t];
-                row[3] = (float)(tx()[t] - lx); row[4] = (float)(ty()[t] - ly);
+                if constexpr (IRB) {
+                    double x = 0., y = 0.;
+#pragma unroll
+                    for (int c = 0; c < NTC; c++) if (c == (t >> 6)) { x = xy.x[c]; y = xy.y[c]; }   // (t = chunk * 64 + lane)
+                    row[3] = (float)(x - lx); row[4] = (float)(y - ly);
+                } else { row[3] = (float)(tx()[t] - lx); row[4] = (float)(ty()[t] - ly); }
             }
         });
         allmasked = __all(allmasked);
@@ -835,7 +877,7 @@ struct Sim {
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
                                                       RouteLog log = RouteLog{nullptr, nullptr, nullptr, 0}, int log_row = 0,
                                                       bool no_grouping = false, int host_actions = 0,
-                                                      bool incremental = false, bool track = false) const {
+                                                      bool incremental = false, bool track = false, const XY* xyp = nullptr) const {
         // host_actions: 0 = the action comes from the device's own valid-action policy (persistent kernel); 1 = from the host
         // (lockstep API): ANY action in [0, T] is simulated as TaskEnv.step would (env/task_env.py:326-342 has no mask check) --
         // on a masked task (feasible, or status <= 0 incl. the stale status of quirk Q3, :192-200) vacancy <= 0 sends the
@@ -892,7 +934,7 @@ struct Sim {
                 nm++;
             }
             if (action == 0) { tx_ = ((const Hdr*)base)->depot_x; ty_ = ((const Hdr*)base)->depot_y; }
-            else { tx_ = tx()[k]; ty_ = ty()[k]; }
+            else task_xy(k, *xyp, tx_, ty_);
         }
         PH_MARK(11);
         // agent_step for every member (:300-324); independent per agent.  The fp64 arithmetic (distance, sqrt, division) runs
@@ -1056,7 +1098,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    S.load_record(rec, lane);
+    typename Sim<CA, CT, RS>::XY xy;
+    S.load_record(rec, lane, xy);
     WSYNC();
     S.set_ablog(ablog, e, S.BA(A), S.BT(T), lane);
     S.set_retlog(nullptr, 0, e, lane);
@@ -1086,7 +1129,8 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     const Lay L = S.L();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    S.load_record(rec, lane);
+    typename Sim<CA, CT, RS>::XY xy;
+    S.load_record(rec, lane, xy);
     WSYNC();
     HdrRegs h = load_hdr(smem);
     float* ag = agents_out ? agents_out + (size_t)e * 6 * BA : nullptr;
@@ -1098,7 +1142,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
         typename Sim<CA, CT, RS>::AMask gm;
         leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
     }
-    if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk);
+    if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk, xy);
     else S.write_inactive_obs(lane, ag, tk, mk);
     if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
     if (lane == 0) {
@@ -1132,7 +1176,8 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     const int nf = nfol_in ? nfol_in[e] : -1;
         // (plain loads, not the non-temporal ones of the persistent kernel: with the record read AND rewritten every launch the
     //  default L2 policy measured 5.5 % faster at 65 536 envs, same at 4096)
-    S.template load_record<false>(rec, lane);
+    typename Sim<CA, CT, RS>::XY xy;
+    S.template load_record<false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) *S.dirty() = 0;
@@ -1149,7 +1194,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
             PH_DECL;
             S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, nf,
                                 fol_in ? fol_in + (size_t)e * DCM_FOLLOWER_COLS : nullptr, summary + (size_t)e * 8 PH_PASS,
-                                log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true);
+                                log, e * BA, (mode & DCM_PARAM_NO_GROUPING) != 0, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true, &xy);
             PHK_MARK(2);                           // apply + updates + advance (+ terminal)
             PHK_INNER();
             // DCM_PARAM_AUTO_RESET: the episode has just ended (its results are in the summary row) -> start the next one from
@@ -1212,13 +1257,13 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 float* sag = (float*)(smem + L.marr());
                 float* stk = sag + 6 * S.A();
                 uint8_t* smk = (uint8_t*)(stk + 5 * (S.T() + 1));
-                S.observe(h, lane, leader, ag ? sag : nullptr, tk ? stk : nullptr, mk ? smk : nullptr);
+                S.observe(h, lane, leader, ag ? sag : nullptr, tk ? stk : nullptr, mk ? smk : nullptr, xy);
                 WSYNC();
                 if (ag) for (int i = lane; i < 6 * S.A(); i += WAVE) ag[i] = sag[i];
                 if (tk) for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) tk[i] = stk[i];
                 if (mk) for (int i = lane; i <= S.T(); i += WAVE) mk[i] = smk[i];
             } else {
-                S.observe(h, lane, leader, ag, tk, mk);
+                S.observe(h, lane, leader, ag, tk, mk, xy);
             }
         } else {
             S.write_inactive_obs(lane, ag, tk, mk);
@@ -1252,7 +1297,8 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     S.scr = Sim<CA, CT, RS>::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    S.template load_record<true, false>(rec, lane);
+    typename Sim<CA, CT, RS>::XY xy;
+    S.template load_record<true, false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
     if (lane == 0) S.inc_state()[1] = -1;  // incremental task_update: nothing is known about the last call of the previous launch
@@ -1290,11 +1336,11 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
             PH_MARK(0);
-            S.observe(h, lane, leader, ag, tk, mk);
+            S.observe(h, lane, leader, ag, tk, mk, xy);
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
             PH_MARK(2);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, 0, true);
+            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, 0, true, false, &xy);
             gd += GAMMA;
             left--;
         }
@@ -1596,7 +1642,7 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT, RS)                                                                                              \
-    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp, \
+    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
                        env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch)
     DISPATCH_ENV(env, CALL);
 #undef CALL
@@ -1629,7 +1675,7 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
 #define CALL(CA, CT, RS)                                                                                                \
-    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env),            \
+    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env),            \
                        env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
                        (const int32_t*)env->sizes, env->p.flags)
     DISPATCH_ENV(env, CALL);
@@ -1647,7 +1693,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
 #define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,   \
+    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
                        active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch, \
                        env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
@@ -1664,7 +1710,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
 #define CALL(CA, CT, RS)                                                                                              \
     hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
-                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : env->L.lds_rec()), (hipStream_t)stream, DIMS(env), \
+                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
     DISPATCH_ENV(env, CALL);
