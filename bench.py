@@ -191,9 +191,10 @@ class SubBatch:
             # routes only over the tasks that can ever become visible under the schedule (the reference's cap hides the rest)
             self.routes, self.route_len = synthetic_route_arrays(self.inst["req"], A, max_task=min(T, visibility[3]) if reactive else None)
             self.env.set_visibility(*visibility)
-            # synthetic routes send exactly req[t] <= 5 agents to task t: 6 member slots per task suffice (an overflow would be
-            # flagged, checked after the run), and at 100A/500T they make the env fit three times into a CU's LDS instead of twice
-            self.env.load_route_arrays(self.routes, self.route_len, member_cap=6)
+            # synthetic routes send exactly req[t] <= 5 agents to task t, so a task never lists more than 5 members: 5 member slots
+            # per task (an overflow would be flagged, checked after the run) -- at 100A/500T the env then fits four times into a
+            # CU's LDS, one wave per SIMD
+            self.env.load_route_arrays(self.routes, self.route_len, member_cap=5)
         else:
             self.ring = self.env.enable_return_log(cfg["episodes"])          # every episode's return of a pass
             self.env.reset(self.seeds, observe=False)

@@ -324,7 +324,7 @@ def config5(B=1024, A=100, T=500):
     out = {}
     for reactive in (False, True):
         env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**inst)
-        env.load_routes([synthetic_routes(inst["req"][b], A, max_task=100 if reactive else None) for b in range(B)], member_cap=6)
+        env.load_routes([synthetic_routes(inst["req"][b], A, max_task=100 if reactive else None) for b in range(B)], member_cap=5)
         env.execute_routes(reactive)
         sync(); t0 = time.perf_counter()
         r = env.execute_routes(reactive)

@@ -6,9 +6,14 @@
 // (capped at 100) when reactive.  This is the deterministic known-answer path of the reference (the
 // CTAS-D routes reproduce testSet_20A_50T_CONDET/metrics/metrics.csv:2) and BASELINE config 5.
 //
-// One wavefront per env, the whole episode in one launch, state in LDS only (instance fields are read from
-// the env record that dcm_load_instances filled).  Unlike RL mode a task may collect more members than its
-// requirement, so member slots are sized by `member_cap` (<= 32) and walked with runtime loops.
+// One wavefront per env, the whole episode in one launch, the state the event loop works on in LDS (instance
+// fields are read from the env record that dcm_load_instances filled).  Unlike RL mode a task may collect more
+// members than its requirement, so member slots are sized by `member_cap` (<= 32) and walked with runtime loops.
+//
+// The kernel runs one wave per SIMD at best (LDS capacity), i.e. every instruction costs its full issue latency
+// (~4 clocks) and every dependent LDS access a full round trip (~64): what counts is the number of both per agent
+// step.  Like task_update, agent_update is therefore incremental after an agent_step (only the agents whose inputs
+// the step changed are recomputed), and each phase issues its LDS reads back to back before it uses any of them.
 #include "common.hpp"
 
 using namespace dcm;
@@ -35,21 +40,21 @@ struct RLay {
     __device__ uint32_t nx() const { return 72 * A; }                      // f64[A] x, y of the agent's NEXT preset target
     __device__ uint32_t ny() const { return 80 * A; }
     __device__ uint32_t tb() const { return 88 * A; }
-    __device__ uint32_t ts() const { return tb(); }
-    __device__ uint32_t tf() const { return tb() + 8 * T; }
-    __device__ uint32_t tw() const { return tb() + 8 * T; }                // terminal only: overwrites time_finish once that is out
-    __device__ uint32_t marr() const { return tb() + 16 * T; }             // f64[MR][T]
+    __device__ uint32_t tf() const { return tb(); }
+    __device__ uint32_t tw() const { return tb(); }                        // terminal only: overwrites time_finish once that is out
+    __device__ uint32_t marr() const { return tb() + 8 * T; }              // f64[MR][T]; terminal: time_start comes back into slot row 0
     __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
     __device__ uint32_t tnab() const { return tinfo() + 4 * T; }           // u32[T]
     __device__ uint32_t mid() const { return tnab() + 4 * T; }             // u8[MR][T]
-    __device__ uint32_t ablog() const { return align16(mid() + MR * T); }  // u16[A][AB_CAP] abandonment log
 };
-// The read-only instance arrays (task x, y, duration: 24 T bytes) stay in the HBM record -- a task's duration is read once, when
-// it becomes feasible; the coordinates of an agent's next target are staged per agent when its route is popped -- and the
-// per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 6: 52.6 KB per env = THREE resident waves per
-// CU instead of the two of rounds 1-2 (74 KB with member_cap 8 and everything in LDS); the kernel is latency-bound.
+// What the event loop does not touch stays out of LDS: the read-only instance arrays (task x, y, duration: 24 T bytes) in the HBM
+// record -- a task's duration is read once, when it becomes feasible; the coordinates of an agent's next target are staged per
+// agent when its route is popped -- and time_start (written once per task, read by the terminal metrics) and the abandonment log
+// (appended to by the rare removal path, read by the terminal metrics) in the handle's per-env HBM scratch; the
+// per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 5 (the largest requirement): 39.3 KB per env =
+// FOUR resident waves per CU, one per SIMD (rounds 1-2: two, with 74 KB; round 3 at first: three, with 51 KB).
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16(align16((uint32_t)(88 * A + 16 * T + 8 * MR * T + 8 * T + MR * T)) + 2u * AB_CAP * A);
+    return align16((uint32_t)(88 * A + 8 * T + 8 * MR * T + 8 * T + MR * T));
 }
 
 struct RP {
@@ -69,11 +74,30 @@ __device__ double py_floordiv(double vx, double wx) {
     return fl;
 }
 
+// -DDCM_REPLAY_PHASES (tools/replay_phases.py, a separate build): shader clocks per phase of the event loop, summed per env and
+// left in the first eight time_start entries of the env.  The s_memtime marks cost a scalar-memory round trip each: read the
+// shares, not the totals.
+#ifdef DCM_REPLAY_PHASES
+#define RPH_DECL uint64_t rph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rph_t = __builtin_readcyclecounter()
+#define RPH(i) do { const uint64_t t_ = __builtin_readcyclecounter(); rph_acc[i] += t_ - rph_t; rph_t = t_; } while (0)
+#define RPH_COUNT(i) (rph_acc[i] += 1)
+#else
+#define RPH_DECL
+#define RPH(i)
+#define RPH_COUNT(i)
+#endif
+
+__device__ __forceinline__ double rl(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 struct Rep {
     int A, T, MR;
     unsigned char* b;
     RLay L;
     const double *gtx, *gty, *gtd;     // task x, y, duration of this env in its HBM record (read-only)
+    double* gts;                       // time_start[T] and
+    uint16_t* gab;                     // the abandonment log u16[A][AB_CAP] of this env in the handle's HBM scratch
     __device__ double* ax() const { return (double*)(b + L.ax()); }
     __device__ double* ay() const { return (double*)(b + L.ay()); }
     __device__ double* arr() const { return (double*)(b + L.arr()); }
@@ -85,7 +109,7 @@ struct Rep {
     __device__ uint32_t* ainfo() const { return (uint32_t*)(b + L.ainfo()); }
     __device__ int32_t* phead() const { return (int32_t*)(b + L.phead()); }
     __device__ int32_t* plen() const { return (int32_t*)(b + L.plen()); }
-    __device__ double* ts() const { return (double*)(b + L.ts()); }
+    __device__ double* ts() const { return gts; }
     __device__ double* tf() const { return (double*)(b + L.tf()); }
     __device__ double* nx() const { return (double*)(b + L.nx()); }
     __device__ double* ny() const { return (double*)(b + L.ny()); }
@@ -94,16 +118,17 @@ struct Rep {
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
     __device__ uint32_t* tnab() const { return (uint32_t*)(b + L.tnab()); }
     __device__ uint8_t* mid() const { return (uint8_t*)(b + L.mid()); }
-    __device__ uint16_t* ablog() const { return (uint16_t*)(b + L.ablog()); }
+    __device__ uint16_t* ablog() const { return gab; }
 
     // tinfo[t]: bits 0-7 requirements, 8-15 status (int8), 16-23 len(members), 24 feasible, 25 finished
 
-    // env/task_env.py:245-281 for ONE task (lane-private); returns true when the call changed the member list or made the
-    // task feasible -- the only cases in which an immediate second call at the same `now` can change it again (a Q1-skipped
-    // member / stale status after the spread branch / `finished` of a task that has just become feasible, :273)
-    __device__ bool task_update_one(int t, double now, double mwt) const {
+    // env/task_env.py:245-281 for ONE task (lane-private).  Bit 0 of the result: the call changed the member list or made the
+    // task feasible at a `now` at which it is already over -- the only cases in which an immediate second call at the same `now`
+    // can change it again (a Q1-skipped member / stale status after the spread branch / `finished` of a task that has just
+    // become feasible, :273).  Bit 1: the task became feasible; bit 2: members were removed -- the two things agent_update reads.
+    __device__ uint32_t task_update_one(int t, double now, double mwt) const {
         uint32_t info = tinfo()[t];
-        bool touched = false;
+        bool touched = false, became = false, removed = false;
         if (!(info & T_FEAS)) {                                              // :249
             const int req = info & 0xFF;
             const int n = (info >> 16) & 0xFF;                               // :250
@@ -116,6 +141,7 @@ struct Rep {
                 if (mx - mn <= mwt) {                                        // :255
                     const double tfin = mx + gtd[t];
                     ts()[t] = mx; tf()[t] = tfin; info |= T_FEAS;            // :256-258
+                    became = true;
                     touched = now >= tfin;   // only a task that is already over changes again at this `now` (finished, :273)
                 } else {
                     const double thr = mx - mwt;                             // :262
@@ -144,14 +170,51 @@ struct Rep {
                 }
                 tnab()[t] += (uint32_t)(n - k);
                 nn = k;
-                touched = true;
+                touched = true; removed = true;
             }
             info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
         } else if (now >= tf()[t]) {
             info |= T_FIN;                                                   // :273-274
         }
         tinfo()[t] = info;
-        return touched;
+        return (touched ? 1u : 0u) | (became ? 2u : 0u) | (removed ? 4u : 0u);
+    }
+
+    // The same for the task an agent_step has just touched, from registers: the whole wave works on task k with what the step has
+    // already read -- `info` = the task's word as the step left it, tf_k = its finish time (if it is feasible), v = on lane j the
+    // arrival time of member slot j (j < len(members), the new member's included), dur = its duration -- so the common outcomes
+    // (still waiting for members; now complete and feasible) cost no LDS round trip at all.  A call that has to remove members
+    // (rare) is handed to task_update_one.  Same result bits.
+    __device__ __forceinline__ uint32_t task_update_joined(int k, uint32_t info, double tf_k, double v, double dur, double now,
+                                                           double mwt, int lane) const {
+        if (info & T_FEAS) {                                                 // :273-274
+            if (!(info & T_FIN) && now >= tf_k && lane == 0) tinfo()[k] = info | T_FIN;
+            return 0;
+        }
+        const int req = info & 0xFF, n = (info >> 16) & 0xFF, status = req - n;   // :250-252
+        bool became = false, touched = false, removal;
+        if (status <= 0) {                                                   // :254
+            double mx = -__builtin_inf(), mn = __builtin_inf();
+            for (int j = 0; j < n; j++) { const double vj = rl(v, j); mx = vj > mx ? vj : mx; mn = vj < mn ? vj : mn; }
+            removal = !(mx - mn <= mwt);                                     // :255 / :262 (the earliest arrival is then <= max - mwt)
+            if (!removal) {
+                const double tfin = mx + dur;
+                if (lane == 0) { ts()[k] = mx; tf()[k] = tfin; }             // :256-258
+                info |= T_FEAS;
+                became = true;
+                touched = now >= tfin;       // only a task that is already over changes again at this `now` (finished, :273)
+            }
+        } else {
+            removal = __ballot(lane < n && now - v >= mwt) != 0;             // :268-271: the first such member is always removed
+        }
+        if (removal) {
+            uint32_t r = 0;
+            if (lane == 0) r = task_update_one(k, now, mwt);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+        }
+        info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)n << 16);
+        if (lane == 0) tinfo()[k] = info;
+        return (touched ? 1u : 0u) | (became ? 2u : 0u);
     }
 
     // task_update (:245-281).  only == -1: every task, like the reference.  only >= 0 / -2: the call that follows an
@@ -159,30 +222,35 @@ struct Rep {
     // agent has just joined (`only`; -2 = it went to the depot) is at a fixed point of task_update and is skipped, which
     // turns the T/64 lane passes of this call into one.  n_infeas carries the number of tasks that are not feasible
     // (feasible_assignment never reverts), for np.all(feasible) of the depot check :279.
-    __device__ void task_update(double now, double mwt, int lane, int only, bool& redo, int& n_infeas) const {
+    // what (out): what the call changed of the things agent_update derives the agents' next decisions from -- TU_FULL after a pass
+    // over every task (anything), else TU_BECAME (task `only` became feasible) and / or TU_REMOVED (it lost members), or 0.
+    static constexpr uint32_t TU_FULL = 1u, TU_BECAME = 2u, TU_REMOVED = 4u;
+    // (info_k, tf_k, slot_v, dur_k: what task_update_joined takes, for only >= 0.)
+    __device__ void task_update(double now, double mwt, int lane, int only, bool& redo, int& n_infeas, uint32_t& what,
+                                uint32_t info_k = 0, double tf_k = 0.0, double slot_v = 0.0, double dur_k = 0.0) const {
         bool touched = false;
+        what = only == -1 ? TU_FULL : 0u;
         if (only == -1) {
             int infeas = 0;
+#pragma nounroll
             for (int t0 = 0; t0 < T; t0 += WAVE) {
                 const int t = t0 + lane;
                 bool inf = false;
-                if (t < T) { touched = task_update_one(t, now, mwt) || touched; inf = !(tinfo()[t] & T_FEAS); }
+                if (t < T) { touched = (task_update_one(t, now, mwt) & 1u) || touched; inf = !(tinfo()[t] & T_FEAS); }
                 infeas += __popcll(__ballot(inf));
             }
             n_infeas = infeas;
         } else if (only >= 0) {
-            bool became = false;
-            if (lane == (only & 63)) {
-                const bool was = tinfo()[only] & T_FEAS;
-                touched = task_update_one(only, now, mwt);
-                became = !was && (tinfo()[only] & T_FEAS);
-            }
-            if (__any(became)) n_infeas -= 1;
+            const uint32_t r = uni(task_update_joined(only, info_k, tf_k, slot_v, dur_k, now, mwt, lane));
+            touched = r & 1u;
+            if (r & 2u) { n_infeas -= 1; what |= TU_BECAME; }
+            if (r & 4u) what |= TU_REMOVED;
         }
         redo = __any(touched);
         const bool all_feasible = n_infeas == 0;
         WSYNC();
         if (all_feasible) {                                                  // depot :277-280 (uniform; false until the very end)
+#pragma nounroll
             for (int a = lane; a < A; a += WAVE) {
                 const uint32_t ai = ainfo()[a];
                 if ((ai & A_INDEPOT) && now >= arr()[a]) ainfo()[a] = ai | A_RETURNED;
@@ -190,74 +258,101 @@ struct Rep {
         }
     }
 
-    // env/task_env.py:207-243 including the reactive depot branch :213-224
+    // env/task_env.py:207-243 including the reactive depot branch :213-224.
+    // mode AU_FULL: every agent, like the reference.  The calls that follow an agent_step of agent `single` at an unchanged `now`
+    // need less: an agent's branch below reads its own fields, the feasibility flag and times of its current task, its membership
+    // flag and all(feasible[:visible]); if the task_update in between changed none of these for anybody else (what == 0) only
+    // that agent is recomputed (AU_ONE, on lane 0); if it made the joined task k feasible, its listed members are as well
+    // (AU_TASK, one per lane) -- everybody else would read what it read in the previous call and store what it stored.
+    // ninf_vis (in/out) = number of infeasible tasks among the visible ones, counted by AU_FULL and maintained by the caller
+    // (a flip of all(feasible[:visible]) changes every depot agent: the caller then asks for AU_FULL).
+    // (agent['assigned'] :232-240 is not kept: nothing on the replay path reads it.)
+    static constexpr int AU_ONE = 0, AU_TASK = 1, AU_FULL = 2;
     __device__ void agent_update(double now, double mwt, int reactive, int visible, int lane, uint32_t& flags, int vis_batch,
-                                 int vis_period) const {
-        bool allf_vis = true;
-        if (reactive) {                                                      // :214 all(feasible[:visible_length])
+                                 int vis_period, int mode, int k, int single, int& ninf_vis) const {
+        if (reactive && mode == AU_FULL) {                                   // :214 all(feasible[:visible_length])
             const int lim = visible < T ? visible : T;
-            for (int t = lane; t < lim; t += WAVE) allf_vis = allf_vis && (tinfo()[t] & T_FEAS);
-            allf_vis = __all(allf_vis);
+            int cnt = 0;
+#pragma nounroll
+            for (int t0 = 0; t0 < lim; t0 += WAVE) {
+                const int t = t0 + lane;
+                cnt += __popcll(__ballot(t < lim && !(tinfo()[t < lim ? t : 0] & T_FEAS)));
+            }
+            ninf_vis = cnt;
+        }
+        const bool allf_vis = ninf_vis == 0;
+        int a_first = lane, a_stop = A;
+        if (mode != AU_FULL) {
+            const int nk = mode == AU_TASK ? (int)((tinfo()[k] >> 16) & 0xFF) : 0;
+            a_first = lane < nk ? (int)mid()[lane * T + k] : (lane == nk ? single : A);
+            a_stop = a_first < A ? a_first + 1 : 0;
         }
         bool terr = false;
-        for (int a = lane; a < A; a += WAVE) {
-            const int c = cur()[a];
+        // (next - 1) // batch of :221 for 0 <= next - 1 < 65536 and 2 <= batch < 65536 is one multiply-high by this constant
+        const uint32_t magic = vis_batch >= 2 && vis_batch < 65536 ? 0xFFFFFFFFu / (uint32_t)vis_batch + 1u : 0u;
+        for (int a = a_first; a < a_stop; a += WAVE) {
+            // what either branch reads about the agent: one LDS round trip; then its current task's words: a second one
+            const int c = cur()[a], len = plen()[a], head = phead()[a];
+            const uint32_t ai = ainfo()[a];
+            const double arrv = arr()[a], nxtd = aw()[a];                    // (aw: the next preset action, staged by the kernel)
+            const int cc = c >= 0 ? c : 0;
+            const uint32_t info = tinfo()[cc];
+            const double tfc = tf()[cc];
             if (c == -2) continue;                                           // :209
-            uint32_t ai = ainfo()[a];
+            double v;
             if (c == -1) {                                                   // :212
-                if (!reactive || allf_vis) { nd()[a] = __builtin_nan(""); continue; }   // :215,:226
-                const int len = plen()[a], head = phead()[a];
-                if (len >= 0 && head >= len) { nd()[a] = __builtin_nan(""); continue; }  // :217-218
-                if (len < 0) { terr = true; continue; }                      // :220 TypeError in the reference
-                // next preset action is read by the caller-provided pointer; stored in aw() scratch by the kernel
-                const int next_action = (int)aw()[a];                        // staged by stage_next()
-                int q = (next_action - 1) / vis_batch;                       // :221 python floor division
-                if ((next_action - 1) % vis_batch != 0 && (next_action - 1) < 0) q--;
-                const double ndt = (double)(q * vis_period);
-                double v = arr()[a];                                         // :222 np.max([...])
-                v = ndt > v ? ndt : v;
-                v = now > v ? now : v;
-                nd()[a] = v;
-                ainfo()[a] = ai & ~A_INDEPOT;                                // :223-224 depot['members'].remove
-                continue;
-            }
-            const uint32_t info = tinfo()[c];                                // :228
-            const bool member = (info & T_FEAS) && (ai & A_MEMBER);          // :229-230
-            if (member) {
-                nd()[a] = tf()[c];                                           // :231
-                if (now >= ts()[c]) ai |= A_ASSIGNED;                        // :232-233
+                if (!reactive || allf_vis || (len >= 0 && head >= len)) v = __builtin_nan("");   // :215,:226 / :217-218
+                else if (len < 0) { terr = true; continue; }                 // :220 TypeError in the reference
+                else {
+                    const int x = (int)nxtd - 1;
+                    int q;                                                   // :221 python floor division
+                    if (magic && x >= 0 && x < 65536) q = (int)__umulhi((uint32_t)x, magic);
+                    else { q = x / vis_batch; if (x % vis_batch != 0 && x < 0) q--; }
+                    const double ndt = (double)(q * vis_period);
+                    v = arrv;                                                // :222 np.max([...])
+                    v = ndt > v ? ndt : v;
+                    v = now > v ? now : v;
+                    ainfo()[a] = ai & ~A_INDEPOT;                            // :223-224 depot['members'].remove
+                }
             } else {
-                nd()[a] = arr()[a] + mwt;                                    // :235/:238
-                ai &= ~A_ASSIGNED;                                           // :236/:240
+                const bool member = (info & T_FEAS) && (ai & A_MEMBER);      // :228-230
+                v = member ? tfc : arrv + mwt;                               // :231 / :235,:238
             }
-            ainfo()[a] = ai;
+            nd()[a] = v;
         }
         if (__any(terr)) flags |= R_TYPE_ERROR;
     }
 };
 
-__global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, int MR, RP P, const unsigned char* state,
+// <CA, CT, CMR> = the batch's agents / tasks / member slots as compile-time constants (every LDS offset and loop bound folds), or
+// <0, 0, 0> = read from the arguments.
+template <int CA, int CT, int CMR>
+__global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT, int MR_, RP P, const unsigned char* state,
                                                 const int32_t* routes, const int32_t* route_len, int route_cap,
                                                 double* summary, int64_t* steps_out, uint32_t* flags_out,
                                                 uint8_t* finished, double* time_start, double* time_finish,
                                                 double* task_wait, int32_t* n_members, double* agent_wait,
-                                                double* travel_dist, uint8_t* returned) {
+                                                double* travel_dist, uint8_t* returned, unsigned char* gscr) {
     const int e = blockIdx.x, lane = threadIdx.x;
+    const int A = CA ? CA : A_, T = CT ? CT : T_, MR = CMR ? CMR : MR_;
     const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
     const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
-          (const double*)(rec + EL.tdur())};
+          (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
+          (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort())};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
     // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance
     {
         const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
+#pragma nounroll
         for (int t = lane; t < T; t += WAVE) {
             const uint32_t req = gti[t] & 0xFF;
             R.tinfo()[t] = req | (req << 8);
             R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0;
         }
+#pragma nounroll
         for (int a = lane; a < A; a += WAVE) {
             R.ax()[a] = depot_x; R.ay()[a] = depot_y; R.arr()[a] = 0.0; R.amax()[a] = 0.0; R.nd()[a] = 0.0; R.tdist()[a] = 0.0;
             R.aw()[a] = 0.0; R.cur()[a] = -2; R.ainfo()[a] = 0; R.phead()[a] = 0;
@@ -277,6 +372,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     // aw()[a] (scratch until the terminal metrics) holds the next preset action of agent a: staged once for everybody,
     // then refreshed only for the agent that pops its route (its entry is the only one that changes), with the global
     // load issued at the pop and consumed after the updates so that its latency hides behind task_update/agent_update
+#pragma nounroll
     for (int a = lane; a < A; a += WAVE) {
         const int len = R.plen()[a];
         const int32_t first = (len > 0) ? my_routes[(size_t)a * route_cap] : 0;
@@ -286,34 +382,57 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
         R.ny()[a] = task ? R.gty[first - 1] : depot_y;
     }
     WSYNC();
+    uint32_t tu_what = 0;
+    int ninf_vis = 0;
+    RPH_DECL;
+    // next_decision_time of the lane's agents (NaN beyond A) and their minimum: read once per event, by check_finished, and used
+    // again by next_decision of the following event (nothing changes them in between)
+    double ndv[AW_MAX], tmin;
+    auto read_next_decisions = [&]() {
+        double lmin = __builtin_nan("");
+#pragma unroll
+        for (int i = 0; i < AW_MAX; i++) {
+            const int a = i * WAVE + lane;
+            ndv[i] = R.nd()[a < A ? a : 0];
+            if (a >= A) ndv[i] = __builtin_nan("");
+            lmin = nanmin2(lmin, ndv[i]);
+        }
+        tmin = wave_nanmin(lmin);
+    };
+    auto latest_arrival = [&]() {                                           // max(x) if x else 0 over the whole arrival lists
+        double lmax = 0.0;
+#pragma nounroll
+        for (int a = lane; a < A; a += WAVE) { const double av = R.amax()[a]; lmax = av > lmax ? av : lmax; }
+        return wave_nanmax(lmax);
+    };
+    read_next_decisions();
+    // visible = clip(now // period * batch + initial) :567 changes only when `now` leaves [vis_lo, vis_hi) = q * period .. (q + 1) *
+    // period (the float floor division is exact for these magnitudes): the fmod / division sequence runs once per window
+    double vis_lo = __builtin_inf(), vis_hi = -__builtin_inf();
     while (!finished_flag && now < P.cutoff) {                               // :565
-        if (P.reactive) {                                                    // :566-567
-            double v = py_floordiv(now, (double)P.vis_period) * (double)P.vis_batch + (double)P.vis_initial;
+        RPH(5); RPH_COUNT(6);
+        if (P.reactive && !(now >= vis_lo && now < vis_hi)) {                // :566-567
+            const double q = py_floordiv(now, (double)P.vis_period);
+            vis_lo = q * (double)P.vis_period; vis_hi = (q + 1.0) * (double)P.vis_period;
+            double v = q * (double)P.vis_batch + (double)P.vis_initial;
             v = v < (double)P.vis_initial ? (double)P.vis_initial : v; v = v > (double)P.vis_cap ? (double)P.vis_cap : v;
             visible = (int)v;
         }
         // next_decision :283-289
-        double lmin = __builtin_nan(""), lmax = 0.0;
-        for (int a = lane; a < A; a += WAVE) {
-            lmin = nanmin2(lmin, R.nd()[a]);
-            const double av = R.amax()[a];                                   // max(x) if x else 0 over the whole list
-            lmax = av > lmax ? av : lmax;
-        }
-        const double tmin = wave_nanmin(lmin);
         const bool any = (tmin == tmin);
-        now = any ? tmin : wave_nanmax(lmax);                                // :569
+        now = any ? tmin : latest_arrival();                                 // :569
         // deciding set (exact ==), fixed before the updates like the reference's `decision_agents`
         uint64_t dm[AW_MAX];
 #pragma unroll
-        for (int i = 0; i < AW_MAX; i++) {
-            const int a = i * 64 + lane;
-            dm[i] = __ballot(any && a < A && R.nd()[a < A ? a : 0] == tmin);
-        }
+        for (int i = 0; i < AW_MAX; i++) dm[i] = __ballot(any && ndv[i] == tmin);
         WSYNC();
-        R.task_update(now, mwt, lane, -1, redo, n_infeas);                   // :570
+        RPH(0);
+        R.task_update(now, mwt, lane, -1, redo, n_infeas, tu_what);          // :570
         WSYNC();
-        R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period);          // :571
+        RPH(1);
+        R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period, Rep::AU_FULL, -1, -1, ninf_vis);   // :571
         WSYNC();
+        RPH(3);
         if (flags & R_TYPE_ERROR) break;
         if (!any) { if (++guard > 8) { flags |= DCM_FLAG_TRUNCATED; break; } } else guard = 0;
 #pragma unroll
@@ -322,14 +441,19 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
             while (m) {                                                      // :572 for agent in decision_agents
                 const int a = i * 64 + __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
-                const int len = uni(R.plen()[a]), head = uni(R.phead()[a]);
+                // everything the step reads about agent a, in ONE LDS round trip (wave-uniform addresses, broadcast reads)
+                const int len_v = R.plen()[a], head_v = R.phead()[a], cur_old = R.cur()[a];
+                const double nxt_v = R.aw()[a], sx = R.nx()[a], sy = R.ny()[a], px = R.ax()[a], py = R.ay()[a], td = R.tdist()[a],
+                             amx = R.amax()[a];
+                uint32_t ai = R.ainfo()[a];
+                const int len = uni(len_v), head = uni(head_v);
                 int action;
                 bool popped = false;
                 int32_t upcoming = 0;
                 double up_x = depot_x, up_y = depot_y;
                 if (len < 0 || head >= len) action = 0;                      // :573-577
                 else {
-                    const int nxt = (int)uni(R.aw()[a]);                     // == my_routes[a][head]
+                    const int nxt = (int)uni(nxt_v);                         // == my_routes[a][head]
                     if (P.reactive && nxt > visible) action = 0;             // :578-584
                     else {
                         action = nxt; popped = true;                         // :585 pop(0)
@@ -343,66 +467,96 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
                     }
                 }
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
-                // agent_step :300-324
+                // agent_step :300-324.  Second round trip, in flight during the distance arithmetic: the joined task's info word
+                // and, one per lane, its member ids.
+                const int k = action - 1, kk = k >= 0 ? k : 0;
+                uint32_t info = R.tinfo()[kk];
+                const int mine = lane < MR ? (int)R.mid()[lane * T + kk] : -1;
+                double slot_v = R.marr()[(lane < MR ? lane : 0) * T + kk];              // lane j: arrival time of member slot j
+                const double tf_k = uni(R.tf()[kk]);
+                const double dur_k = R.gtd[kk];              // (from HBM, needed only if the task becomes feasible in this step)
                 // target of a popped action = the coordinates staged for this agent (see `upcoming` below); a forced depot visit
                 // (route exhausted / next task not yet visible) leaves them in place for later
-                const double tx_ = action ? uni(R.nx()[a]) : depot_x, ty_ = action ? uni(R.ny()[a]) : depot_y;
-                // (distance, sqrt and division on all lanes -- broadcast LDS reads, wave-uniform values -- and only the stores on
-                //  lane 0: gfx950 runs fp64 VALU instructions with fewer than 16 active lanes 4x slower, profiles/r03_calib)
-                const double d = dist2(R.ax()[a], R.ay()[a], tx_, ty_);
+                const double tx_ = action ? sx : depot_x, ty_ = action ? sy : depot_y;
+                // (distance, sqrt and division on all lanes -- wave-uniform values -- and only the stores on lane 0: gfx950 runs
+                //  fp64 VALU instructions with fewer than 16 active lanes 4x slower, profiles/r03_calib)
+                const double d = dist2(px, py, tx_, ty_);
                 const double arrival = now + over_velocity(d);                      // :315,:318
-                const double tdist_new = R.tdist()[a] + d;                          // :317
-                WSYNC();
+                const double tdist_new = td + d;                                    // :317
+                ai = uni(ai) & ~A_MEMBER; info = uni(info);
+                int pos = -1;
+                bool fresh = false;
+                if (action == 0) ai |= A_INDEPOT;                            // :321-322
+                else {
+                    int n = (info >> 16) & 0xFF;
+                    const uint64_t hit = __ballot(lane < n && mine == a);
+                    pos = hit ? 63 - __clzll((long long)hit) : -1;           // (the last matching slot, like a scan would find)
+                    if (pos < 0) {
+                        if (n >= MR) flags |= DCM_FLAG_OVERFLOW;
+                        else { pos = n++; fresh = true; }
+                    }
+                    if (pos >= 0) ai |= A_MEMBER;
+                    info = (info & ~0x00FF0000u) | ((uint32_t)n << 16);
+                }
+                const bool joined = pos >= 0;
+                if (joined && lane == pos) slot_v = arrival;
                 if (lane == 0) {
                     R.tdist()[a] = tdist_new;
                     R.arr()[a] = arrival;
                     // a member released by its task finishing before it arrived re-decides early, so the list is
                     // not monotone in replays with surplus visitors; :286 takes the max over the whole list
-                    if (R.cur()[a] == -2 || arrival > R.amax()[a]) R.amax()[a] = arrival;
+                    if (cur_old == -2 || arrival > amx) R.amax()[a] = arrival;
                     R.ax()[a] = tx_; R.ay()[a] = ty_;                        // :320
-                    R.cur()[a] = action - 1;                                 // :314
-                    uint32_t ai = R.ainfo()[a] & ~A_MEMBER;
-                    if (action == 0) ai |= A_INDEPOT;                        // :321-322
-                    else {
-                        const int k = action - 1;
-                        uint32_t info = R.tinfo()[k];
-                        int n = (info >> 16) & 0xFF, pos = -1;
-                        for (int j = 0; j < n; j++) if (R.mid()[j * T + k] == a) pos = j;
-                        if (pos < 0) {
-                            if (n >= MR) flags |= DCM_FLAG_OVERFLOW;
-                            else { pos = n++; R.mid()[pos * T + k] = (uint8_t)a; }
-                        }
-                        if (pos >= 0) { R.marr()[pos * T + k] = arrival; ai |= A_MEMBER; }
-                        R.tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16);
-                    }
+                    R.cur()[a] = k;                                          // :314
                     R.ainfo()[a] = ai;
+                    if (action) {
+                        if (fresh) R.mid()[pos * T + k] = (uint8_t)a;
+                        if (joined) R.marr()[pos * T + k] = arrival;
+                        R.tinfo()[k] = info;
+                    }
                 }
-                flags |= (uint32_t)__builtin_amdgcn_readlane((int)flags, 0);
                 if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
                 WSYNC();
-                R.task_update(now, mwt, lane, redo ? -1 : (action > 0 ? action - 1 : -2), redo, n_infeas);   // :575/:582/:586
+                RPH(4); RPH_COUNT(7);
+#ifdef DCM_REPLAY_PHASES
+                const bool full_ = redo;
+#endif
+                R.task_update(now, mwt, lane, redo ? -1 : (action > 0 ? action - 1 : -2), redo, n_infeas, tu_what, info, tf_k, slot_v,
+                              dur_k);                                        // :575/:582/:586
                 if (popped && lane == 0) { R.aw()[a] = (double)upcoming; R.nx()[a] = up_x; R.ny()[a] = up_y; }   // before agent_update: its reactive branch reads aw
                 WSYNC();
-                R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period);  // :576/:583/:587
+#ifdef DCM_REPLAY_PHASES
+                if (full_) RPH(1); else RPH(2);
+#endif
+                int au_mode = Rep::AU_ONE;
+                if (tu_what & (Rep::TU_FULL | Rep::TU_REMOVED)) au_mode = Rep::AU_FULL;
+                else if (tu_what & Rep::TU_BECAME) {
+                    au_mode = Rep::AU_TASK;
+                    if (P.reactive && action - 1 < visible && --ninf_vis == 0) au_mode = Rep::AU_FULL;   // all(feasible[:visible]) flips
+                }
+                if (au_mode == Rep::AU_ONE && action > 0) {
+                    // the common case written out: only agent a changes, and what its branch of agent_update reads is at hand
+                    const uint32_t info2 = R.tinfo()[k];
+                    const double tfk = R.tf()[k];
+                    if (lane == 0) R.nd()[a] = ((info2 & T_FEAS) && joined) ? tfk : arrival + mwt;        // :229-238
+                } else
+                    R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period, au_mode, k, a,
+                                   ninf_vis);                                // :576/:583/:587
                 WSYNC();
+                RPH(3);
                 if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
             }
             if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
         }
         if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
         // check_finished :366-373,:588
-        double l2 = __builtin_nan(""), m2 = 0.0;
-        bool allret = true;
-        for (int a = lane; a < A; a += WAVE) {
-            l2 = nanmin2(l2, R.nd()[a]);
-            const double av = R.amax()[a];
-            m2 = av > m2 ? av : m2;
-            allret = allret && (R.ainfo()[a] & A_RETURNED);
-        }
-        const double t2 = wave_nanmin(l2);
-        if (!(t2 == t2)) {
-            now = wave_nanmax(m2);
-            bool allfin = true;
+        read_next_decisions();
+        if (!(tmin == tmin)) {
+            now = latest_arrival();
+            bool allret = true, allfin = true;
+#pragma nounroll
+            for (int a = lane; a < A; a += WAVE) allret = allret && (R.ainfo()[a] & A_RETURNED);
+#pragma nounroll
             for (int t = lane; t < T; t += WAVE) allfin = allfin && (R.tinfo()[t] & T_FIN);
             finished_flag = __all(allret) && __all(allfin);
         } else finished_flag = false;
@@ -412,6 +566,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     if (time_finish) for (int t = lane; t < T; t += WAVE) time_finish[(size_t)e * T + t] = R.tf()[t];
     WSYNC();
     // ---- get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
+#pragma nounroll
     for (int t = lane; t < T; t += WAVE) {
         const uint32_t info = R.tinfo()[t];
         const int n = (info >> 16) & 0xFF;
@@ -437,6 +592,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     // :358-364 per agent in the reference's order: tasks ascending, member term first, then +max_waiting_time per
     // entry of the agent in that task's abandoned_agent list (entries from the abandonment log, sorted by task id)
     bool over = false;
+#pragma nounroll
     for (int a = lane; a < A; a += WAVE) {
         const uint32_t nab = R.ainfo()[a] >> 16;
         const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
@@ -450,6 +606,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
         }
         int p = 0;
         double s = 0.0;
+#pragma nounroll
         for (int t = 0; t < T; t++) {
             const uint32_t info = R.tinfo()[t];
             const int n = (info >> 16) & 0xFF;
@@ -471,12 +628,17 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
     if (__any(over)) flags |= DCM_FLAG_WAIT_ORDER;
     WSYNC();
     int nfin = 0;
+#pragma nounroll
     for (int t0 = 0; t0 < T; t0 += WAVE) {
         const int t = t0 + lane;
         nfin += __popcll(__ballot(t < T && (R.tinfo()[t < T ? t : 0] & T_FIN)));
     }
+    // time_start comes back from the HBM scratch into member-slot row 0 (the waiting sums above were its last readers)
+#pragma nounroll
+    for (int t = lane; t < T; t += WAVE) R.marr()[t] = R.ts()[t];
+    WSYNC();
     const double Td = (double)T, Ad = (double)A;
-    const double m2 = psum<4>(R.ts(), T) / Td, m3 = psum<4>(R.aw(), A) / Ad, m4 = psum<4>(R.tdist(), A),
+    const double m2 = psum<4>(R.marr(), T) / Td, m3 = psum<4>(R.aw(), A) / Ad, m4 = psum<4>(R.tdist(), A),
                  m5 = psum<4>(R.tw(), T) / Td;
     if (lane == 0) {
         double* row = summary + (size_t)e * 8;
@@ -485,20 +647,31 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A, int T, int PA, int PT, i
         if (steps_out) steps_out[e] = steps;
         if (flags_out) flags_out[e] = flags | DCM_FLAG_DONE | (finished_flag ? DCM_FLAG_FINISHED : 0u);
     }
+#pragma nounroll
     for (int t = lane; t < T; t += WAVE) {
         const size_t o = (size_t)e * T + t;
         const uint32_t info = R.tinfo()[t];
         if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
-        if (time_start) time_start[o] = R.ts()[t];
+        if (time_start) time_start[o] = R.marr()[t];
         if (task_wait) task_wait[o] = R.tw()[t];
         if (n_members) n_members[o] = (info >> 16) & 0xFF;
     }
+#pragma nounroll
     for (int a = lane; a < A; a += WAVE) {
         const size_t o = (size_t)e * A + a;
         if (agent_wait) agent_wait[o] = R.aw()[a];
         if (travel_dist) travel_dist[o] = R.tdist()[a];
         if (returned) returned[o] = (R.ainfo()[a] & A_RETURNED) ? 1 : 0;
     }
+#ifdef DCM_REPLAY_PHASES
+    WSYNC();
+    if (time_start && lane < 8) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (lane == q) v = (double)rph_acc[q];
+        time_start[(size_t)e * T + lane] = v;
+    }
+#endif
 }
 
 }  // namespace
@@ -540,11 +713,19 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
     if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");
     const uint32_t lds = replay_lds_bytes(env->A, env->T, env->member_cap);
-    (void)hipFuncSetAttribute((const void*)k_replay, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
     RP P{100.0, 200.0, reactive ? 1 : 0, env->vis[0], env->vis[1], env->vis[2], env->vis[3]};  // env/task_env.py:564-565,567
-    hipLaunchKernelGGL(k_replay, GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T, env->member_cap, P, env->state,
-                       env->routes, env->route_len, env->route_cap, env->summary, steps_out, flags_out, finished, time_start,
-                       time_finish, task_wait, n_members, agent_wait, travel_dist, returned);
+#define REPLAY(CA, CT, CMR)                                                                                                  \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)k_replay<CA, CT, CMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_replay<CA, CT, CMR>), GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T,  \
+                           env->member_cap, P, env->state, env->routes, env->route_len, env->route_cap, env->summary,      \
+                           steps_out, flags_out, finished, time_start, time_finish, task_wait, n_members, agent_wait,       \
+                           travel_dist, returned, env->gscratch);                                                          \
+    } while (0)
+    if (env->A == 100 && env->T == 500 && env->member_cap == 5) REPLAY(100, 500, 5);   // BASELINE config 5
+    else REPLAY(0, 0, 0);
+#undef REPLAY
     LAUNCH_OK();
     return DCM_OK;
 }

@@ -58,8 +58,11 @@ def test_ctasd_routes_known_answer(gpu_device, golden_dir, reactive, fixture):
 from dcmrta_amd.instances import synthetic_routes  # noqa: E402
 
 
-@pytest.mark.parametrize("A,T,reactive", [(100, 500, False), (100, 500, True), (100, 100, True), (50, 200, True), (13, 37, False)])
-def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
+@pytest.mark.parametrize("A,T,reactive,cap", [(100, 500, False, 8), (100, 500, True, 8), (100, 100, True, 8), (50, 200, True, 8),
+                                              (13, 37, False, 8),
+                                              # bench.py --config 5's setting: 5 member slots = four resident waves per CU
+                                              (100, 500, False, 5), (100, 500, True, 5)])
+def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive, cap):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
     B = 3
@@ -67,7 +70,7 @@ def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive):
     rl = [synthetic_routes(inst["req"][b], A, max_task=100 if reactive else None) for b in range(B)]
     env = BatchedTaskEnv(B, A, T, device=gpu_device)
     env.load_instances(**inst)
-    env.load_routes(rl, member_cap=8)
+    env.load_routes(rl, member_cap=cap)
     out = env.execute_routes(reactive=reactive)
     flags = out["flags"].cpu().numpy()
     assert not (flags & 0x78).any()

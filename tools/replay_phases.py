@@ -30,7 +30,7 @@ env = BatchedTaskEnv(B, A, T, device="cuda:0")
 env.load_instances(**inst)
 routes, route_len = synthetic_route_arrays(inst["req"], A, max_task=min(T, vis[3]) if reactive else None)
 env.set_visibility(*vis)
-env.load_route_arrays(routes, route_len, member_cap=6)
+env.load_route_arrays(routes, route_len, member_cap=5)
 for _ in range(2):
     out = env.execute_routes(reactive, fields=("time_start",))
 torch.cuda.synchronize()
