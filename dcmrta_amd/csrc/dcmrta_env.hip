@@ -143,7 +143,10 @@ struct Sim {
     __device__ __forceinline__ double* ty() const { return (double*)(base + L().ty()); }
     __device__ __forceinline__ double* tdur() const { return (double*)(base + (IRB ? L().tx() : L().tdur())); }   // IRB image: no x / y sections
     __device__ __forceinline__ uint32_t aux_off() const { return IRB ? L().tx() + 8u * (uint32_t)PT() : L().aux(); }
-    static __host__ __device__ constexpr uint32_t lds_image_bytes(Lay l) { return IRB ? l.tx() + 8u * (uint32_t)l.T + 48u : l.lds_rec(); }
+    // (+ 4 T bytes of wake-up times, see task_update, for the layouts with more than one lane chunk of tasks)
+    static __host__ __device__ constexpr uint32_t lds_image_bytes(Lay l) {
+        return (IRB ? l.tx() + 8u * (uint32_t)l.T + 48u : l.lds_rec()) + ((CT == 0 || CT > WAVE) ? align16(4u * (uint32_t)l.T) : 0u);
+    }
     // coordinates of task k (wave-uniform k): lane k & 63 of chunk k >> 6 holds them, or the LDS image does
     __device__ __forceinline__ void task_xy(int k, const XY& xy, double& x, double& y) const {
         if constexpr (IRB) {
@@ -259,8 +262,18 @@ struct Sim {
     // the call only revisits the 64-task lane chunks the previous call touched (bitmask in inc_state()[1]) plus the chunk
     // of `only`; every other task is at a fixed point of task_update.  inc_state()[0] carries the number of infeasible
     // tasks for np.all(feasible) :279.
+    // only == -3: the call of a NEW event (advance(): `now` has moved, no agent_step in between).  With the time alone a task that
+    // was at a fixed point changes in two ways only: a feasible one finishes (now >= time_finish :273), or the earliest member of
+    // an infeasible one has waited max_waiting_time (now - arrival >= mwt :269; also a member the rounding of that expression
+    // left listed when its agent moved on).  Every visit of a task therefore leaves the time of its next possible change --
+    // time_finish, or min(arrival) + mwt, +inf if neither applies, -inf if the visit itself removed members -- rounded DOWN to
+    // fp32 (a margin of 1e-7 relative, far above the rounding of the two fp64 expressions) in wake()[t], an LDS-only array behind
+    // the record image; the call of a new event compares `now` with it and visits the lane chunks with a due task plus those the
+    // previous call touched, instead of all of them (one or two of the four at 50A/200T).  tools/inc_selfcheck.py dry-runs
+    // every skipped task.
     static constexpr bool INC = (CT == 0 || CT > WAVE);
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + aux_off() + 8); }
+    __device__ __forceinline__ float* wake() const { return (float*)(base + aux_off() + 48); }    // f32[PT], INC kernels only
     // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..M member-arrival row j,
     // bit 6 member ids, bit 7 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
     static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_IDS = 1u << 6, DIRTY_NAB = 1u << 7, DIRTY_ALL = 0xFFu;
@@ -337,6 +350,12 @@ struct Sim {
                 info |= (now >= tfin) ? T_FIN : 0u;                          // :273-274
             }
             tinfo()[t] = info;
+            if constexpr (INC) {
+                // when can the time alone change this task next?  (mn: the earliest listed arrival; NaN without members)
+                double w = (info & T_FEAS) ? ((info & T_FIN) ? __builtin_inf() : (feas0 ? tfin : mx + dur)) : mn + mwt;
+                w = (w == w) ? w : __builtin_inf();
+                wake()[t] = any_drop ? -__builtin_inff() : __double2float_rd(w);
+            }
             allf = allf && (info & T_FEAS);
             // a freshly feasible task only changes again at this `now` if it is already over (finished is evaluated one
             // call later, :273): now >= time_finish needs zero duration and every member already there
@@ -351,7 +370,14 @@ struct Sim {
             int32_t* st = inc_state();
             const uint32_t nchunk = (uint32_t)(T_ + WAVE - 1) / WAVE, all = nchunk >= 32 ? ~0u : ((1u << nchunk) - 1u);
             uint32_t todo = all;
-            if (only != -1 && T_ > WAVE) {
+            if (only == -3 && T_ > WAVE) {
+                uint32_t cand = 0;
+                for (uint32_t ch = 0; ch < nchunk; ch++) {
+                    const int t = (int)(ch * WAVE) + lane;
+                    cand |= __ballot(t < T_ && now >= (double)wake()[t < T_ ? t : 0]) ? (1u << ch) : 0u;
+                }
+                todo = ((uint32_t)uni(st[1]) | cand) & all;
+            } else if (only != -1 && only != -3 && T_ > WAVE) {
                 todo = ((uint32_t)uni(st[1]) | (only >= 0 ? (1u << (only >> 6)) : 0u)) & all;
             }
             const bool full = todo == all;
@@ -722,7 +748,7 @@ struct Sim {
             }
             WSYNC();
             PH_MARK(6);
-            task_update(h, P, lane, -1, track);                               // worker.py:50
+            task_update(h, P, lane, -3, track);                               // worker.py:50
             WSYNC();
             PH_MARK(7);
             agent_update(h, P, lane);                                         // worker.py:51
@@ -741,6 +767,7 @@ struct Sim {
     // reset + clear_decisions (env/task_env.py:116-140); keeps seed, d, episodes
     __device__ __forceinline__ void reset_state(HdrRegs& h, int lane) const {
         const int PT_ = PT();
+        if constexpr (INC) { if (lane == 0) inc_state()[1] = -1; }   // incremental task_update: the next call visits every task
         for_tasks(lane, [&](int t) {
             const uint32_t req = tinfo()[t] & 0xFF;
             tinfo()[t] = req | (req << 8);       // status = requirements :131, members [], not feasible/finished
@@ -1542,7 +1569,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : (h->A <= 64 && h->T <= 64) ? Lay{64, 64} : Lay{h->A, h->T};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
-    if (h->L.lds_rec() > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
+    if (h->L.lds_rec() + align16(4u * (uint32_t)h->L.T) > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
     const size_t bytes = (size_t)params->n_envs * h->L.rec_bytes();
     hipError_t e1 = hipMalloc((void**)&h->state, bytes);
     hipError_t e2 = hipMalloc((void**)&h->summary, (size_t)params->n_envs * 8 * sizeof(double));
@@ -1568,7 +1595,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     static std::mutex lds_mutex;                 // handles are created from several host threads (one actor thread per GPU)
     std::lock_guard<std::mutex> lds_guard(lds_mutex);
     const int dev_slot = params->device & 63;
-    int lds = (int)h->L.lds_rec();
+    int lds = (int)(h->L.lds_rec() + align16(4u * (uint32_t)h->L.T));   // (+ the wake-up times of the multi-chunk layouts)
     if (h->L.lds_bytes() <= 10240) lds = (int)h->L.lds_bytes();           // persistent kernel of the small layouts: scratch in LDS
     if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
     lds_limit[dev_slot] = lds;
