@@ -44,13 +44,14 @@ struct RLay {
     __device__ uint32_t tw() const { return tb(); }                        // terminal only: overwrites time_finish once that is out
     __device__ uint32_t marr() const { return tb() + 8 * T; }              // f64[MR][T]; terminal: time_start comes back into slot row 0
     __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
-    __device__ uint32_t tnab() const { return tinfo() + 4 * T; }           // u32[T]
-    __device__ uint32_t mid() const { return tnab() + 4 * T; }             // u8[MR][T]
+    __device__ uint32_t wake() const { return tinfo() + 4 * T; }           // f32[T] earliest time a task_update call can change the task
+    __device__ uint32_t mid() const { return wake() + 4 * T; }             // u8[MR][T]
 };
 // What the event loop does not touch stays out of LDS: the read-only instance arrays (task x, y, duration: 24 T bytes) in the HBM
 // record -- a task's duration is read once, when it becomes feasible; the coordinates of an agent's next target are staged per
-// agent when its route is popped -- and time_start (written once per task, read by the terminal metrics) and the abandonment log
-// (appended to by the rare removal path, read by the terminal metrics) in the handle's per-env HBM scratch; the
+// agent when its route is popped -- and time_start (written once per task, read by the terminal metrics), the abandonment log
+//  and the per-task abandonment counts (appended to by the rare removal path, read by the terminal metrics) in the
+// handle's per-env HBM scratch; the
 // per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 5 (the largest requirement): 39.3 KB per env =
 // FOUR resident waves per CU, one per SIMD (rounds 1-2: two, with 74 KB; round 3 at first: three, with 51 KB).
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
@@ -96,8 +97,9 @@ struct Rep {
     unsigned char* b;
     RLay L;
     const double *gtx, *gty, *gtd;     // task x, y, duration of this env in its HBM record (read-only)
-    double* gts;                       // time_start[T] and
-    uint16_t* gab;                     // the abandonment log u16[A][AB_CAP] of this env in the handle's HBM scratch
+    double* gts;                       // time_start[T],
+    uint16_t* gab;                     // the abandonment log u16[A][AB_CAP] and
+    uint32_t* gnab;                    // the abandonment counts u32[T] of this env in the handle's HBM scratch
     __device__ double* ax() const { return (double*)(b + L.ax()); }
     __device__ double* ay() const { return (double*)(b + L.ay()); }
     __device__ double* arr() const { return (double*)(b + L.arr()); }
@@ -116,7 +118,8 @@ struct Rep {
     __device__ double* tw() const { return (double*)(b + L.tw()); }
     __device__ double* marr() const { return (double*)(b + L.marr()); }
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
-    __device__ uint32_t* tnab() const { return (uint32_t*)(b + L.tnab()); }
+    __device__ uint32_t* tnab() const { return gnab; }
+    __device__ float* wake() const { return (float*)(b + L.wake()); }
     __device__ uint8_t* mid() const { return (uint8_t*)(b + L.mid()); }
     __device__ uint16_t* ablog() const { return gab; }
 
@@ -129,6 +132,7 @@ struct Rep {
     __device__ uint32_t task_update_one(int t, double now, double mwt) const {
         uint32_t info = tinfo()[t];
         bool touched = false, became = false, removed = false;
+        double w = __builtin_inf();          // earliest time at which a later call can change the task if nobody joins it
         if (!(info & T_FEAS)) {                                              // :249
             const int req = info & 0xFF;
             const int n = (info >> 16) & 0xFF;                               // :250
@@ -143,16 +147,21 @@ struct Rep {
                     ts()[t] = mx; tf()[t] = tfin; info |= T_FEAS;            // :256-258
                     became = true;
                     touched = now >= tfin;   // only a task that is already over changes again at this `now` (finished, :273)
+                    w = tfin;
                 } else {
                     const double thr = mx - mwt;                             // :262
                     for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }
                 }
             } else {
                 bool skip = false;                                           // :268-271 (quirk Q1)
+                double mn = __builtin_inf();
                 for (int j = 0; j < n; j++) {
+                    const double v = marr()[j * T + t];
+                    mn = v < mn ? v : mn;
                     if (skip) { skip = false; continue; }
-                    if (now - marr()[j * T + t] >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
+                    if (now - v >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
                 }
+                w = mn + mwt;                // the earliest member's limit (+inf without members)
             }
             int nn = n;
             if (changed) {
@@ -171,12 +180,16 @@ struct Rep {
                 tnab()[t] += (uint32_t)(n - k);
                 nn = k;
                 touched = true; removed = true;
+                w = -__builtin_inf();        // the next call looks again (stale status byte, a Q1-skipped member)
             }
             info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
-        } else if (now >= tf()[t]) {
-            info |= T_FIN;                                                   // :273-274
+        } else if (!(info & T_FIN)) {
+            const double tfin = tf()[t];
+            if (now >= tfin) info |= T_FIN;                                  // :273-274
+            else w = tfin;
         }
         tinfo()[t] = info;
+        wake()[t] = __double2float_rd(w);
         return (touched ? 1u : 0u) | (became ? 2u : 0u) | (removed ? 4u : 0u);
     }
 
@@ -188,14 +201,14 @@ struct Rep {
     __device__ __forceinline__ uint32_t task_update_joined(int k, uint32_t info, double tf_k, double v, double dur, double now,
                                                            double mwt, int lane) const {
         if (info & T_FEAS) {                                                 // :273-274
-            if (!(info & T_FIN) && now >= tf_k && lane == 0) tinfo()[k] = info | T_FIN;
+            if (!(info & T_FIN) && now >= tf_k && lane == 0) { tinfo()[k] = info | T_FIN; wake()[k] = __builtin_inff(); }
             return 0;
         }
         const int req = info & 0xFF, n = (info >> 16) & 0xFF, status = req - n;   // :250-252
         bool became = false, touched = false, removal;
+        double mx = -__builtin_inf(), mn = __builtin_inf(), w;
+        for (int j = 0; j < n; j++) { const double vj = rl(v, j); mx = vj > mx ? vj : mx; mn = vj < mn ? vj : mn; }
         if (status <= 0) {                                                   // :254
-            double mx = -__builtin_inf(), mn = __builtin_inf();
-            for (int j = 0; j < n; j++) { const double vj = rl(v, j); mx = vj > mx ? vj : mx; mn = vj < mn ? vj : mn; }
             removal = !(mx - mn <= mwt);                                     // :255 / :262 (the earliest arrival is then <= max - mwt)
             if (!removal) {
                 const double tfin = mx + dur;
@@ -203,9 +216,11 @@ struct Rep {
                 info |= T_FEAS;
                 became = true;
                 touched = now >= tfin;       // only a task that is already over changes again at this `now` (finished, :273)
+                w = tfin;
             }
         } else {
             removal = __ballot(lane < n && now - v >= mwt) != 0;             // :268-271: the first such member is always removed
+            w = mn + mwt;
         }
         if (removal) {
             uint32_t r = 0;
@@ -213,7 +228,7 @@ struct Rep {
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
         }
         info = (info & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)n << 16);
-        if (lane == 0) tinfo()[k] = info;
+        if (lane == 0) { tinfo()[k] = info; wake()[k] = __double2float_rd(w); }
         return (touched ? 1u : 0u) | (became ? 2u : 0u);
     }
 
@@ -231,13 +246,30 @@ struct Rep {
         bool touched = false;
         what = only == -1 ? TU_FULL : 0u;
         if (only == -1) {
-            int infeas = 0;
+            // Every visit of a task leaves in wake()[t] the earliest time at which a later call can change it (time_finish; the
+            // earliest member's arrival + max_waiting_time; -inf after a removal: stale status byte, Q1-skipped member; +inf if
+            // nothing is pending), rounded DOWN to fp32 -- a margin far above the rounding of the fp64 expressions it stands for.
+            // A task with now < wake is at a fixed point of task_update_one, so the pass reads the wake-up times of 512 tasks in one
+            // LDS round trip and visits the due ones: one or two lanes per event instead of all T tasks.
+            int infeas = n_infeas;
 #pragma nounroll
-            for (int t0 = 0; t0 < T; t0 += WAVE) {
-                const int t = t0 + lane;
-                bool inf = false;
-                if (t < T) { touched = (task_update_one(t, now, mwt) & 1u) || touched; inf = !(tinfo()[t] & T_FEAS); }
-                infeas += __popcll(__ballot(inf));
+            for (int tb = 0; tb < T; tb += 8 * WAVE) {
+                float wk[8];
+                const int nc = (T - tb + WAVE - 1) / WAVE < 8 ? (T - tb + WAVE - 1) / WAVE : 8;
+#pragma unroll
+                for (int c = 0; c < 8; c++) if (c < nc) { const int t = tb + c * WAVE + lane; wk[c] = wake()[t < T ? t : 0]; }
+                uint32_t due = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) if (c < nc) { if (tb + c * WAVE + lane < T && now >= (double)wk[c]) due |= 1u << c; }
+#pragma nounroll
+                for (int c = 0; c < nc; c++) {
+                    const bool act = (due >> c) & 1u;
+                    if (!__any(act)) continue;
+                    uint32_t r = 0;
+                    if (act) r = task_update_one(tb + c * WAVE + lane, now, mwt);
+                    touched = touched || (r & 1u);
+                    infeas -= __popcll(__ballot(r & 2u));                    // became feasible
+                }
             }
             n_infeas = infeas;
         } else if (only >= 0) {
@@ -339,7 +371,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
           (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
-          (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort())};
+          (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort()),
+          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx())};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
@@ -350,7 +383,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
         for (int t = lane; t < T; t += WAVE) {
             const uint32_t req = gti[t] & 0xFF;
             R.tinfo()[t] = req | (req << 8);
-            R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0;
+            R.tnab()[t] = 0; R.ts()[t] = 0.0; R.tf()[t] = 0.0; R.wake()[t] = __builtin_inff();
         }
 #pragma nounroll
         for (int a = lane; a < A; a += WAVE) {
@@ -513,6 +546,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                         if (fresh) R.mid()[pos * T + k] = (uint8_t)a;
                         if (joined) R.marr()[pos * T + k] = arrival;
                         R.tinfo()[k] = info;
+                        R.wake()[k] = -__builtin_inff();                     // its member list changed: the next task_update visits it
                     }
                 }
                 if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
