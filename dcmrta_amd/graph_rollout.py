@@ -31,7 +31,8 @@ class GraphedRollout:
         allocations); it is captured together with env.step.  record=True keeps what worker.py:77-83 appends per decision
         (agent / task observation, action, mask, deciding agent, plus the `active` flag of the env) for up to `capacity`
         batched steps.  buckets: fractions of B (descending, first must be 1.0) for which a compacted-policy graph is kept;
-        `policy` must then accept any batch size (it is called as policy(obs_like) with the gathered rows)."""
+        `policy` must then accept any batch size (it is called as policy(obs_like) with the gathered rows; a policy with the
+        attribute wants_rows = True is called as policy(obs_like, rows) with the env indices of those rows, None = all)."""
         self.env, self.policy, self.check_every = env, policy, int(check_every)
         B, A, T, dev = env.B, env.A, env.T, env.device
         self.action = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -79,7 +80,7 @@ class GraphedRollout:
             idx = self.idx[n]
             sub = type(obs)(obs.agents.index_select(0, idx), obs.tasks.index_select(0, idx), obs.mask.index_select(0, idx),
                             obs.leader.index_select(0, idx), obs.active.index_select(0, idx))
-            a = self.policy(sub)
+            a = self.policy(sub, idx) if getattr(self.policy, "wants_rows", False) else self.policy(sub)
             self.action.index_copy_(0, idx, a.to(torch.int32))
         if self.rec is not None:
             r, i = self.rec, self.slot

@@ -39,7 +39,7 @@ class EnvError(RuntimeError):
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
                  rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets=None, episode_stride=None,
-                 env_offset=0, strict_mask=False):
+                 env_offset=0, strict_mask=False, twin_rollout=False):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
@@ -56,6 +56,11 @@ class BatchedRunner:
         # strict_mask: freeze (and report, EnvError) an env whose policy picks a masked task instead of simulating the action
         # the way the reference's TaskEnv.step does
         self.strict_mask = bool(strict_mask)
+        # twin_rollout: job() plays the sampled episode and its greedy self-critic twin (worker.py:89) of every env in ONE batch
+        # of 2 n_envs (rows [0, B) sample, rows [B, 2B) take the argmax of the same net on the same instance and seed): one
+        # policy forward, one graph replay and one tail per decision instead of two -- what pays when the loop is launch-bound
+        # (small batches) or the tail of finishing episodes is long
+        self.twin_rollout = bool(twin_rollout)
         self.episode_stride = int(episode_stride) if episode_stride is not None else self.B
         self.env_offset = int(env_offset)
         if self.episode_stride < self.B:
@@ -132,6 +137,8 @@ class BatchedRunner:
             return lambda logp, mask: torch.argmax(logp - torch.empty_like(logp).exponential_(1.0).log(), dim=1)
         if mode == "greedy":      # worker.py:228
             return lambda logp, mask: torch.argmax(logp, dim=1)
+        if mode == "twin":        # rows below `half` sample, the others take the argmax (see twin_rollout)
+            raise ValueError("the twin selection needs the row split: use _twin_policy")
         if mode == "test":        # worker.py:140 / :185
             return lambda logp, mask: torch.argmax(logp.exp() * ~mask, dim=1)
         raise ValueError(mode)
@@ -153,14 +160,25 @@ class BatchedRunner:
 
     @torch.no_grad()
     def rollout(self, net, slot, seeds, mode, record):
-        """One episode per env under `net`; mode "sample" | "greedy" | "test".  Returns (summary[B,8], rec, n_steps):
-        rec = dict of [n_steps, B, ...] experience tensors (views of the graph's static buffers: consume them before the
-        next recorded rollout of the same shape) or None."""
+        """One episode per env under `net`; mode "sample" | "greedy" | "test" | "twin" (first half of the envs samples, second
+        half is greedy).  Returns (summary[B,8], rec, n_steps): rec = dict of [n_steps, B, ...] experience tensors (views of the
+        graph's static buffers: consume them before the next recorded rollout of the same shape) or None."""
         env = slot["env"]
-        select = self._select(mode)
+        if mode == "twin":
+            # 1 for the sampling rows, 0 for the greedy ones: argmax(logp - gate * log(q)) is the exponential race on the
+            # former and the plain argmax on the latter; `rows` = the env indices a compacted graph runs the policy on
+            gate = slot.setdefault("twin_gate", torch.cat([torch.ones(env.B // 2, 1), torch.zeros(env.B - env.B // 2, 1)]).to(env.device))
 
-        def policy(obs):
-            return select(net(obs.tasks, obs.agents, obs.mask), obs.mask)
+            def policy(obs, rows=None):
+                logp = net(obs.tasks, obs.agents, obs.mask)
+                g = gate if rows is None else gate.index_select(0, rows)
+                return torch.argmax(logp - g.to(logp.dtype) * torch.empty_like(logp).exponential_(1.0).log(), dim=1)
+            policy.wants_rows = True
+        else:
+            select = self._select(mode)
+
+            def policy(obs):
+                return select(net(obs.tasks, obs.agents, obs.mask), obs.mask)
         if not self.use_graph:
             return self._rollout_eager(policy, env, seeds, record)
         key = (id(net), mode, bool(record))
@@ -237,7 +255,7 @@ class BatchedRunner:
         self.set_baseline_weights(baseline_weights)
         A = int(agents_num[1] if isinstance(agents_num, (tuple, list)) else agents_num)
         T = int(tasks_num[1] if isinstance(tasks_num, (tuple, list)) else tasks_num)
-        slot = self._slot(A, T)
+        slot = self._slot(A, T, n_envs=2 * self.B if self.twin_rollout else None)
         env = slot["env"]
         first = self.first_env(episodeNumber)
         ragged = self._is_range(agents_num) or self._is_range(tasks_num)
@@ -247,14 +265,24 @@ class BatchedRunner:
                                          tuple(tasks_num) if isinstance(tasks_num, (tuple, list)) else int(tasks_num))
         else:
             inst = generate_batch(self.B, A, T, base_seed=self.base_seed, first=first)   # worker.py:32
-        env.load_instances(**inst)
         net = self._rollout_net()
         self._set_padding_hint(net, ragged)
         seeds = env_seeds(self.base_seed, first, self.B)
-        summary, rec, n_steps = self.rollout(net, slot, seeds, "sample", record=True)             # run_episode
-        truncated = self._check_flags(env, "sampled rollout")
-        greedy_summary, grec, g_steps = self.rollout(net, slot, seeds, "greedy", record=self.keep_greedy_record)  # baseline_test :89
-        truncated += self._check_flags(env, "greedy baseline rollout")
+        if self.twin_rollout:
+            B = self.B
+            env.load_instances(**{k: (np.concatenate([v, v]) if isinstance(v, np.ndarray) else v) for k, v in inst.items()})
+            summary2, rec2, n_steps = self.rollout(net, slot, np.concatenate([seeds, seeds]), "twin", record=True)
+            truncated = self._check_flags(env, "sampled + greedy twin rollout")
+            summary, greedy_summary = summary2[:B], summary2[B:]
+            rec = {k: v[:, :B] for k, v in rec2.items()}
+            grec = {k: v[:, B:] for k, v in rec2.items()} if self.keep_greedy_record else None
+            g_steps = n_steps
+        else:
+            env.load_instances(**inst)
+            summary, rec, n_steps = self.rollout(net, slot, seeds, "sample", record=True)             # run_episode
+            truncated = self._check_flags(env, "sampled rollout")
+            greedy_summary, grec, g_steps = self.rollout(net, slot, seeds, "greedy", record=self.keep_greedy_record)  # baseline_test :89
+            truncated += self._check_flags(env, "greedy baseline rollout")
         reward, greedy_reward = summary[:, 0], greedy_summary[:, 0]
         advantage = reward - greedy_reward                                         # worker.py:92
         jobResults = self._experience(rec, n_steps, reward, advantage, as_lists)

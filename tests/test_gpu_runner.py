@@ -9,7 +9,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_job_contract_and_replay(gpu_device, oracle_lib):
+@pytest.mark.parametrize("twin", [False, True])
+def test_job_contract_and_replay(gpu_device, oracle_lib, twin):
+    """twin=True: the sampled episodes and their greedy twins played as ONE batch of 2 B envs (BatchedRunner(twin_rollout=True))."""
     from dcmrta_amd.choice import env_seeds
     from dcmrta_amd.instances import generate_batch
     from dcmrta_amd.policy import AttentionNet
@@ -17,7 +19,7 @@ def test_job_contract_and_replay(gpu_device, oracle_lib):
     torch.manual_seed(0)
     B, A, T = 6, 10, 20
     small = lambda: AttentionNet(6, 5, 32)
-    r = BatchedRunner(metaAgentID=3, n_envs=B, device=gpu_device, net_factory=small, base_seed=11)
+    r = BatchedRunner(metaAgentID=3, n_envs=B, device=gpu_device, net_factory=small, base_seed=11, twin_rollout=twin)
     r.keep_greedy_record = True
     w = {k: v.clone() for k, v in r.get_weights().items()}
     jobResults, metrics, info = r.job(w, w, episodeNumber=2, agents_num=A, tasks_num=T, as_lists=True)
