@@ -1621,6 +1621,7 @@ int dcm_destroy(dcm_env* env) {
     if (env->gscratch) (void)hipFree(env->gscratch);
     if (env->routes) (void)hipFree(env->routes);
     if (env->route_len) (void)hipFree(env->route_len);
+    if (env->rmarr) (void)hipFree(env->rmarr);
     if (env->sizes) (void)hipFree(env->sizes);
     delete env;
     return DCM_OK;

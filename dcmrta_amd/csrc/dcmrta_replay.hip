@@ -42,8 +42,7 @@ struct RLay {
     __device__ uint32_t tb() const { return 88 * A; }
     __device__ uint32_t tf() const { return tb(); }
     __device__ uint32_t tw() const { return tb(); }                        // terminal only: overwrites time_finish once that is out
-    __device__ uint32_t marr() const { return tb() + 8 * T; }              // f64[MR][T]; terminal: time_start comes back into slot row 0
-    __device__ uint32_t tinfo() const { return marr() + 8 * MR * T; }      // u32[T]
+    __device__ uint32_t tinfo() const { return tb() + 8 * T; }             // u32[T]
     __device__ uint32_t wake() const { return tinfo() + 4 * T; }           // f32[T] earliest time a task_update call can change the task
     __device__ uint32_t mid() const { return wake() + 4 * T; }             // u8[MR][T]
 };
@@ -55,7 +54,7 @@ struct RLay {
 // per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 5 (the largest requirement): 39.3 KB per env =
 // FOUR resident waves per CU, one per SIMD (rounds 1-2: two, with 74 KB; round 3 at first: three, with 51 KB).
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16((uint32_t)(88 * A + 8 * T + 8 * MR * T + 8 * T + MR * T));
+    return align16((uint32_t)(88 * A + 8 * T + 8 * T + MR * T));
 }
 
 struct RP {
@@ -100,6 +99,7 @@ struct Rep {
     double* gts;                       // time_start[T],
     uint16_t* gab;                     // the abandonment log u16[A][AB_CAP] and
     uint32_t* gnab;                    // the abandonment counts u32[T] of this env in the handle's HBM scratch
+    double* gmarr;                     // member arrival times f64[T][MR] of this env (dcm_load_routes allocates them)
     __device__ double* ax() const { return (double*)(b + L.ax()); }
     __device__ double* ay() const { return (double*)(b + L.ay()); }
     __device__ double* arr() const { return (double*)(b + L.arr()); }
@@ -116,7 +116,7 @@ struct Rep {
     __device__ double* nx() const { return (double*)(b + L.nx()); }
     __device__ double* ny() const { return (double*)(b + L.ny()); }
     __device__ double* tw() const { return (double*)(b + L.tw()); }
-    __device__ double* marr() const { return (double*)(b + L.marr()); }
+    __device__ double& marr(int j, int t) const { return gmarr[t * MR + j]; }
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
     __device__ uint32_t* tnab() const { return gnab; }
     __device__ float* wake() const { return (float*)(b + L.wake()); }
@@ -140,8 +140,8 @@ struct Rep {
             uint32_t keep = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
             bool changed = false;
             if (status <= 0) {                                               // :254
-                double mx = marr()[t], mn = mx;
-                for (int j = 1; j < n; j++) { const double v = marr()[j * T + t]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+                double mx = marr(0, t), mn = mx;
+                for (int j = 1; j < n; j++) { const double v = marr(j, t); mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
                 if (mx - mn <= mwt) {                                        // :255
                     const double tfin = mx + gtd[t];
                     ts()[t] = mx; tf()[t] = tfin; info |= T_FEAS;            // :256-258
@@ -150,13 +150,13 @@ struct Rep {
                     w = tfin;
                 } else {
                     const double thr = mx - mwt;                             // :262
-                    for (int j = 0; j < n; j++) if (marr()[j * T + t] <= thr) { keep &= ~(1u << j); changed = true; }
+                    for (int j = 0; j < n; j++) if (marr(j, t) <= thr) { keep &= ~(1u << j); changed = true; }
                 }
             } else {
                 bool skip = false;                                           // :268-271 (quirk Q1)
                 double mn = __builtin_inf();
                 for (int j = 0; j < n; j++) {
-                    const double v = marr()[j * T + t];
+                    const double v = marr(j, t);
                     mn = v < mn ? v : mn;
                     if (skip) { skip = false; continue; }
                     if (now - v >= mwt) { keep &= ~(1u << j); changed = true; skip = true; }  // :269
@@ -169,7 +169,7 @@ struct Rep {
                 for (int j = 0; j < n; j++) {
                     const uint32_t id = mid()[j * T + t];
                     if (keep & (1u << j)) {
-                        if (k != j) { mid()[k * T + t] = (uint8_t)id; marr()[k * T + t] = marr()[j * T + t]; }
+                        if (k != j) { mid()[k * T + t] = (uint8_t)id; marr(k, t) = marr(j, t); }
                         k++;
                     } else {
                         const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                                                 double* summary, int64_t* steps_out, uint32_t* flags_out,
                                                 uint8_t* finished, double* time_start, double* time_finish,
                                                 double* task_wait, int32_t* n_members, double* agent_wait,
-                                                double* travel_dist, uint8_t* returned, unsigned char* gscr) {
+                                                double* travel_dist, uint8_t* returned, unsigned char* gscr, double* member_arrivals) {
     const int e = blockIdx.x, lane = threadIdx.x;
     const int A = CA ? CA : A_, T = CT ? CT : T_, MR = CMR ? CMR : MR_;
     const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
           (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
           (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort()),
-          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx())};
+          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), member_arrivals + (size_t)e * T * MR};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                 const int k = action - 1, kk = k >= 0 ? k : 0;
                 uint32_t info = R.tinfo()[kk];
                 const int mine = lane < MR ? (int)R.mid()[lane * T + kk] : -1;
-                double slot_v = R.marr()[(lane < MR ? lane : 0) * T + kk];              // lane j: arrival time of member slot j
+                double slot_v = R.marr(lane < MR ? lane : 0, kk);              // lane j: arrival time of member slot j
                 const double tf_k = uni(R.tf()[kk]);
                 const double dur_k = R.gtd[kk];              // (from HBM, needed only if the task becomes feasible in this step)
                 // target of a popped action = the coordinates staged for this agent (see `upcoming` below); a forced depot visit
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                     R.ainfo()[a] = ai;
                     if (action) {
                         if (fresh) R.mid()[pos * T + k] = (uint8_t)a;
-                        if (joined) R.marr()[pos * T + k] = arrival;
+                        if (joined) R.marr(pos, k) = arrival;
                         R.tinfo()[k] = info;
                         R.wake()[k] = -__builtin_inff();                     // its member list changed: the next task_update visits it
                     }
@@ -607,10 +607,10 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
         const double ab = (double)R.tnab()[t] * mwt;
         double s = 0.0;
         if (n != 0) {
-            double mx = R.marr()[t];
-            for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
+            double mx = R.marr(0, t);
+            for (int j = 1; j < n; j++) { const double v = R.marr(j, t); mx = v > mx ? v : mx; }
             const bool feas = info & T_FEAS;
-            auto term = [&](int j) { const double v = R.marr()[j * T + t]; return feas ? (mx - v) : (now - v); };
+            auto term = [&](int j) { const double v = R.marr(j, t); return feas ? (mx - v) : (now - v); };
             if (n < 8) { for (int j = 0; j < n; j++) s += term(j); }
             else {
                 double r[8];
@@ -647,10 +647,10 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
             int pos = -1;
             for (int j = 0; j < n; j++) if (R.mid()[j * T + t] == a) pos = j;
             if (pos >= 0) {
-                const double mine = R.marr()[pos * T + t];
+                const double mine = R.marr(pos, t);
                 if (info & T_FEAS) {
-                    double mx = R.marr()[t];
-                    for (int j = 1; j < n; j++) { const double v = R.marr()[j * T + t]; mx = v > mx ? v : mx; }
+                    double mx = R.marr(0, t);
+                    for (int j = 1; j < n; j++) { const double v = R.marr(j, t); mx = v > mx ? v : mx; }
                     s += mx - mine;                                          // :360
                 } else { const double w = now - mine; s += (w > 0.0) ? w : 0.0; }   // :362
             }
@@ -667,28 +667,30 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
         const int t = t0 + lane;
         nfin += __popcll(__ballot(t < T && (R.tinfo()[t < T ? t : 0] & T_FIN)));
     }
-    // time_start comes back from the HBM scratch into member-slot row 0 (the waiting sums above were its last readers)
-#pragma nounroll
-    for (int t = lane; t < T; t += WAVE) R.marr()[t] = R.ts()[t];
-    WSYNC();
     const double Td = (double)T, Ad = (double)A;
-    const double m2 = psum<4>(R.marr(), T) / Td, m3 = psum<4>(R.aw(), A) / Ad, m4 = psum<4>(R.tdist(), A),
-                 m5 = psum<4>(R.tw(), T) / Td;
+    const double m3 = psum<4>(R.aw(), A) / Ad, m4 = psum<4>(R.tdist(), A), m5 = psum<4>(R.tw(), T) / Td;
+#pragma nounroll
+    for (int t = lane; t < T; t += WAVE) {
+        const size_t o = (size_t)e * T + t;
+        const uint32_t info = R.tinfo()[t];
+        if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
+        if (task_wait) task_wait[o] = R.tw()[t];
+        if (n_members) n_members[o] = (info >> 16) & 0xFF;
+    }
+    WSYNC();
+    // time_start comes back from the HBM scratch into the section the waiting sums have just left (np.nanmean(time_start),
+    // worker.py:105, is one serial pairwise sum: it wants its T inputs an LDS read away)
+    double* const tsl = R.tw();
+#pragma nounroll
+    for (int t = lane; t < T; t += WAVE) { const double v = R.ts()[t]; tsl[t] = v; if (time_start) time_start[(size_t)e * T + t] = v; }
+    WSYNC();
+    const double m2 = psum<4>(tsl, T) / Td;
     if (lane == 0) {
         double* row = summary + (size_t)e * 8;
         row[0] = -now; row[1] = (double)nfin; row[2] = (double)nfin / Td; row[3] = now;
         row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
         if (steps_out) steps_out[e] = steps;
         if (flags_out) flags_out[e] = flags | DCM_FLAG_DONE | (finished_flag ? DCM_FLAG_FINISHED : 0u);
-    }
-#pragma nounroll
-    for (int t = lane; t < T; t += WAVE) {
-        const size_t o = (size_t)e * T + t;
-        const uint32_t info = R.tinfo()[t];
-        if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
-        if (time_start) time_start[o] = R.marr()[t];
-        if (task_wait) task_wait[o] = R.tw()[t];
-        if (n_members) n_members[o] = (info >> 16) & 0xFF;
     }
 #pragma nounroll
     for (int a = lane; a < A; a += WAVE) {
@@ -722,6 +724,8 @@ int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_le
     const size_t nr = (size_t)env->p.n_envs * env->A * route_cap, nl = (size_t)env->p.n_envs * env->A;   // (CHECK_ENV: the handle's device is current)
     if (env->routes) { (void)hipFree(env->routes); env->routes = nullptr; }
     if (env->route_len) { (void)hipFree(env->route_len); env->route_len = nullptr; }
+    if (env->rmarr) { (void)hipFree(env->rmarr); env->rmarr = nullptr; }
+    HIP_TRY(hipMalloc((void**)&env->rmarr, (size_t)env->p.n_envs * env->T * member_cap * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&env->routes, nr * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&env->route_len, nl * sizeof(int32_t)));
     HIP_TRY(hipMemcpyAsync(env->routes, routes, nr * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -755,7 +759,7 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
         hipLaunchKernelGGL((k_replay<CA, CT, CMR>), GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T,  \
                            env->member_cap, P, env->state, env->routes, env->route_len, env->route_cap, env->summary,      \
                            steps_out, flags_out, finished, time_start, time_finish, task_wait, n_members, agent_wait,       \
-                           travel_dist, returned, env->gscratch);                                                          \
+                           travel_dist, returned, env->gscratch, env->rmarr);                                              \
     } while (0)
     if (env->A == 100 && env->T == 500 && env->member_cap == 5) REPLAY(100, 500, 5);   // BASELINE config 5
     else REPLAY(0, 0, 0);
