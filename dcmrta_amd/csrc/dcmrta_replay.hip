@@ -23,38 +23,44 @@ namespace {
 constexpr int MR_MAX = 32;
 constexpr uint32_t R_TYPE_ERROR = DCM_FLAG_TYPE_ERROR;
 
-// LDS layout of the replay state
+// LDS layout of the replay state: what the event loop reads on its critical path.  [0, 48 A) is dead once the loop has ended and
+// then holds the per-task waiting sums / the time_start copy of the terminal metrics (tsc(): behind the layout if 48 A < 8 T).
 struct RLay {
     int A, T, MR;
     __device__ uint32_t ax() const { return 0; }
     __device__ uint32_t ay() const { return 8 * A; }
     __device__ uint32_t arr() const { return 16 * A; }
     __device__ uint32_t nd() const { return 24 * A; }
-    __device__ uint32_t tdist() const { return 32 * A; }
-    __device__ uint32_t aw() const { return 40 * A; }
-    __device__ uint32_t cur() const { return 48 * A; }
-    __device__ uint32_t ainfo() const { return 52 * A; }
-    __device__ uint32_t phead() const { return 56 * A; }
-    __device__ uint32_t plen() const { return 60 * A; }
-    __device__ uint32_t amax() const { return 64 * A; }                    // f64[A] max(arrival_time list), :286
-    __device__ uint32_t nx() const { return 72 * A; }                      // f64[A] x, y of the agent's NEXT preset target
-    __device__ uint32_t ny() const { return 80 * A; }
-    __device__ uint32_t tb() const { return 88 * A; }
-    __device__ uint32_t tf() const { return tb(); }
-    __device__ uint32_t tw() const { return tb(); }                        // terminal only: overwrites time_finish once that is out
-    __device__ uint32_t tinfo() const { return tb() + 8 * T; }             // u32[T]
+    __device__ uint32_t nx() const { return 32 * A; }                      // f64[A] x, y of the agent's NEXT preset target
+    __device__ uint32_t ny() const { return 40 * A; }
+    __device__ uint32_t aw() const { return 48 * A; }
+    __device__ uint32_t cur() const { return 56 * A; }
+    __device__ uint32_t ainfo() const { return 60 * A; }
+    __device__ uint32_t phead() const { return 64 * A; }
+    __device__ uint32_t plen() const { return 68 * A; }
+    __device__ uint32_t tb() const { return 72 * A; }
+    __device__ uint32_t tinfo() const { return tb(); }                     // u32[T]
     __device__ uint32_t wake() const { return tinfo() + 4 * T; }           // f32[T] earliest time a task_update call can change the task
     __device__ uint32_t mid() const { return wake() + 4 * T; }             // u8[MR][T]
+    __device__ uint32_t tsc() const { return 48 * A >= 8 * T ? 0u : (uint32_t)((mid() + MR * T + 7) & ~7); }   // f64[T], terminal only
 };
-// What the event loop does not touch stays out of LDS: the read-only instance arrays (task x, y, duration: 24 T bytes) in the HBM
-// record -- a task's duration is read once, when it becomes feasible; the coordinates of an agent's next target are staged per
-// agent when its route is popped -- and time_start (written once per task, read by the terminal metrics), the abandonment log
-//  and the per-task abandonment counts (appended to by the rare removal path, read by the terminal metrics) in the
-// handle's per-env HBM scratch; the
-// per-task waiting sums reuse the time_finish section.  100A/500T with member_cap 5 (the largest requirement): 39.3 KB per env =
-// FOUR resident waves per CU, one per SIMD (rounds 1-2: two, with 74 KB; round 3 at first: three, with 51 KB).
+// What the event loop does not touch, or touches off its critical path, stays out of LDS.  In the HBM record: the read-only
+// instance arrays (task x, y, duration: a task's duration is read once, when it becomes feasible; the coordinates of an agent's
+// next target are staged per agent when its route is popped).  In the handle's per-env HBM scratch: time_start (written once per
+// task, read by the terminal metrics), the abandonment log and the per-task abandonment counts (rare removal path).
+// In the replay scratch dcm_load_routes allocates (replay_scratch_bytes per env): the member arrival times f64[T][member_cap]
+// (read by the step that joins the task -- one line per task, requested together with the task's LDS words -- and by the task's
+// own update), time_finish f64[T] (the step hands the joined task's value on in registers), travel_dist and
+// max(arrival_time) f64[A] (loaded and stored by the agent's own step, never waited for).  A wave's global accesses are issued
+// and served in order, so the wave sees its own stores (wavefront-scope fences need no cache action).
+// 100A/500T with member_cap 5: 13.7 KB of LDS per env = ELEVEN resident waves per CU (rounds 1-2: two, with 74 KB; round 3 at
+// first three, then four with 39.3 KB -- one wave per SIMD, every instruction and LDS round trip at full latency).
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    return align16((uint32_t)(88 * A + 8 * T + 8 * T + MR * T));
+    const uint32_t loop = (uint32_t)(72 * A + 8 * T + MR * T);
+    return align16(48 * A >= 8 * T ? loop : ((loop + 7u) & ~7u) + 8u * (uint32_t)T);
+}
+__host__ __device__ inline size_t replay_scratch_bytes(int A, int T, int MR) {
+    return (size_t)8 * T * MR + (size_t)8 * T + (size_t)16 * A;
 }
 
 struct RP {
@@ -99,23 +105,24 @@ struct Rep {
     double* gts;                       // time_start[T],
     uint16_t* gab;                     // the abandonment log u16[A][AB_CAP] and
     uint32_t* gnab;                    // the abandonment counts u32[T] of this env in the handle's HBM scratch
-    double* gmarr;                     // member arrival times f64[T][MR] of this env (dcm_load_routes allocates them)
+    double* gmarr;                     // member arrival times f64[T][MR], then time_finish f64[T], travel_dist f64[A] and
+                                       // max(arrival_time) f64[A] of this env (the replay scratch, see RLay)
     __device__ double* ax() const { return (double*)(b + L.ax()); }
     __device__ double* ay() const { return (double*)(b + L.ay()); }
     __device__ double* arr() const { return (double*)(b + L.arr()); }
     __device__ double* nd() const { return (double*)(b + L.nd()); }
-    __device__ double* tdist() const { return (double*)(b + L.tdist()); }
+    __device__ double* tdist() const { return gmarr + (size_t)T * MR + T; }
     __device__ double* aw() const { return (double*)(b + L.aw()); }
-    __device__ double* amax() const { return (double*)(b + L.amax()); }
+    __device__ double* amax() const { return gmarr + (size_t)T * MR + T + A; }
     __device__ int32_t* cur() const { return (int32_t*)(b + L.cur()); }
     __device__ uint32_t* ainfo() const { return (uint32_t*)(b + L.ainfo()); }
     __device__ int32_t* phead() const { return (int32_t*)(b + L.phead()); }
     __device__ int32_t* plen() const { return (int32_t*)(b + L.plen()); }
     __device__ double* ts() const { return gts; }
-    __device__ double* tf() const { return (double*)(b + L.tf()); }
+    __device__ double* tf() const { return gmarr + (size_t)T * MR; }
     __device__ double* nx() const { return (double*)(b + L.nx()); }
     __device__ double* ny() const { return (double*)(b + L.ny()); }
-    __device__ double* tw() const { return (double*)(b + L.tw()); }
+    __device__ double* tw() const { return (double*)(b + L.tsc()); }           // terminal only
     __device__ double& marr(int j, int t) const { return gmarr[t * MR + j]; }
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
     __device__ uint32_t* tnab() const { return gnab; }
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
           (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
           (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort()),
-          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), member_arrivals + (size_t)e * T * MR};
+          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), (double*)((unsigned char*)member_arrivals + (size_t)e * replay_scratch_bytes(A, T, MR))};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
@@ -570,9 +577,9 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                 }
                 if (au_mode == Rep::AU_ONE && action > 0) {
                     // the common case written out: only agent a changes, and what its branch of agent_update reads is at hand
-                    const uint32_t info2 = R.tinfo()[k];
-                    const double tfk = R.tf()[k];
-                    if (lane == 0) R.nd()[a] = ((info2 & T_FEAS) && joined) ? tfk : arrival + mwt;        // :229-238
+                    // (the task_update in between changed nothing about task k -- otherwise tu_what would say so -- so its
+                    //  feasibility flag and finish time are the ones the step read)
+                    if (lane == 0) R.nd()[a] = ((info & T_FEAS) && joined) ? tf_k : arrival + mwt;        // :229-238
                 } else
                     R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period, au_mode, k, a,
                                    ninf_vis);                                // :576/:583/:587
@@ -596,7 +603,6 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
         } else finished_flag = false;
     }
     WSYNC();
-    // time_finish leaves first: its LDS section is reused for the per-task waiting sums
     if (time_finish) for (int t = lane; t < T; t += WAVE) time_finish[(size_t)e * T + t] = R.tf()[t];
     WSYNC();
     // ---- get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
         if (n_members) n_members[o] = (info >> 16) & 0xFF;
     }
     WSYNC();
-    // time_start comes back from the HBM scratch into the section the waiting sums have just left (np.nanmean(time_start),
+    // time_start comes back from the HBM scratch into the LDS scratch the waiting sums have just left (np.nanmean(time_start),
     // worker.py:105, is one serial pairwise sum: it wants its T inputs an LDS read away)
     double* const tsl = R.tw();
 #pragma nounroll
@@ -725,7 +731,7 @@ int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_le
     if (env->routes) { (void)hipFree(env->routes); env->routes = nullptr; }
     if (env->route_len) { (void)hipFree(env->route_len); env->route_len = nullptr; }
     if (env->rmarr) { (void)hipFree(env->rmarr); env->rmarr = nullptr; }
-    HIP_TRY(hipMalloc((void**)&env->rmarr, (size_t)env->p.n_envs * env->T * member_cap * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&env->rmarr, (size_t)env->p.n_envs * replay_scratch_bytes(env->A, env->T, member_cap)));
     HIP_TRY(hipMalloc((void**)&env->routes, nr * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void**)&env->route_len, nl * sizeof(int32_t)));
     HIP_TRY(hipMemcpyAsync(env->routes, routes, nr * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
