@@ -40,8 +40,7 @@ struct RLay {
     __device__ uint32_t plen() const { return 68 * A; }
     __device__ uint32_t tb() const { return 72 * A; }
     __device__ uint32_t tinfo() const { return tb(); }                     // u32[T]
-    __device__ uint32_t wake() const { return tinfo() + 4 * T; }           // f32[T] earliest time a task_update call can change the task
-    __device__ uint32_t mid() const { return wake() + 4 * T; }             // u8[MR][T]
+    __device__ uint32_t mid() const { return tinfo() + 4 * T; }            // u8[MR][T]
     __device__ uint32_t tsc() const { return 48 * A >= 8 * T ? 0u : (uint32_t)((mid() + MR * T + 7) & ~7); }   // f64[T], terminal only
 };
 // What the event loop does not touch, or touches off its critical path, stays out of LDS.  In the HBM record: the read-only
@@ -56,11 +55,11 @@ struct RLay {
 // 100A/500T with member_cap 5: 13.7 KB of LDS per env = ELEVEN resident waves per CU (rounds 1-2: two, with 74 KB; round 3 at
 // first three, then four with 39.3 KB -- one wave per SIMD, every instruction and LDS round trip at full latency).
 __host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    const uint32_t loop = (uint32_t)(72 * A + 8 * T + MR * T);
+    const uint32_t loop = (uint32_t)(72 * A + 4 * T + MR * T);
     return align16(48 * A >= 8 * T ? loop : ((loop + 7u) & ~7u) + 8u * (uint32_t)T);
 }
 __host__ __device__ inline size_t replay_scratch_bytes(int A, int T, int MR) {
-    return (size_t)8 * T * MR + (size_t)8 * T + (size_t)16 * A;
+    return (size_t)8 * T * MR + (size_t)8 * T + (size_t)16 * A + (((size_t)4 * T + 7) & ~(size_t)7);
 }
 
 struct RP {
@@ -126,7 +125,7 @@ struct Rep {
     __device__ double& marr(int j, int t) const { return gmarr[t * MR + j]; }
     __device__ uint32_t* tinfo() const { return (uint32_t*)(b + L.tinfo()); }
     __device__ uint32_t* tnab() const { return gnab; }
-    __device__ float* wake() const { return (float*)(b + L.wake()); }
+    __device__ float* wake() const { return (float*)(gmarr + (size_t)T * MR + T + 2 * A); }   // f32[T] earliest time a task_update call can change the task
     __device__ uint8_t* mid() const { return (uint8_t*)(b + L.mid()); }
     __device__ uint16_t* ablog() const { return gab; }
 
