@@ -83,7 +83,7 @@ __device__ double py_floordiv(double vx, double wx) {
 // left in the first eight time_start entries of the env.  The s_memtime marks cost a scalar-memory round trip each: read the
 // shares, not the totals.
 #ifdef DCM_REPLAY_PHASES
-#define RPH_DECL uint64_t rph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rph_t = __builtin_readcyclecounter()
+#define RPH_DECL uint64_t rph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, rph_t = __builtin_readcyclecounter()
 #define RPH(i) do { const uint64_t t_ = __builtin_readcyclecounter(); rph_acc[i] += t_ - rph_t; rph_t = t_; } while (0)
 #define RPH_COUNT(i) (rph_acc[i] += 1)
 #else
@@ -306,6 +306,21 @@ struct Rep {
     // (a flip of all(feasible[:visible]) changes every depot agent: the caller then asks for AU_FULL).
     // (agent['assigned'] :232-240 is not kept: nothing on the replay path reads it.)
     static constexpr int AU_ONE = 0, AU_TASK = 1, AU_FULL = 2;
+    // :221-222: when a depot agent whose next preset task `next` is not visible yet decides again -- np.max([arrival at the depot,
+    // (next - 1) // batch * period, now])
+    __device__ __forceinline__ static double rearm_time(int next, double arrv, double now, int vis_batch, int vis_period) {
+        // (next - 1) // batch for 0 <= next - 1 < 65536 and 2 <= batch < 65536 is one multiply-high by this constant
+        const uint32_t magic = vis_batch >= 2 && vis_batch < 65536 ? 0xFFFFFFFFu / (uint32_t)vis_batch + 1u : 0u;
+        const int x = next - 1;
+        int q;                                                               // python floor division
+        if (magic && x >= 0 && x < 65536) q = (int)__umulhi((uint32_t)x, magic);
+        else { q = x / vis_batch; if (x % vis_batch != 0 && x < 0) q--; }
+        const double ndt = (double)(q * vis_period);
+        double v = arrv;
+        v = ndt > v ? ndt : v;
+        v = now > v ? now : v;
+        return v;
+    }
     __device__ void agent_update(double now, double mwt, int reactive, int visible, int lane, uint32_t& flags, int vis_batch,
                                  int vis_period, int mode, int k, int single, int& ninf_vis) const {
         if (reactive && mode == AU_FULL) {                                   // :214 all(feasible[:visible_length])
@@ -326,8 +341,6 @@ struct Rep {
             a_stop = a_first < A ? a_first + 1 : 0;
         }
         bool terr = false;
-        // (next - 1) // batch of :221 for 0 <= next - 1 < 65536 and 2 <= batch < 65536 is one multiply-high by this constant
-        const uint32_t magic = vis_batch >= 2 && vis_batch < 65536 ? 0xFFFFFFFFu / (uint32_t)vis_batch + 1u : 0u;
         for (int a = a_first; a < a_stop; a += WAVE) {
             // what either branch reads about the agent: one LDS round trip; then its current task's words: a second one
             const int c = cur()[a], len = plen()[a], head = phead()[a];
@@ -342,14 +355,7 @@ struct Rep {
                 if (!reactive || allf_vis || (len >= 0 && head >= len)) v = __builtin_nan("");   // :215,:226 / :217-218
                 else if (len < 0) { terr = true; continue; }                 // :220 TypeError in the reference
                 else {
-                    const int x = (int)nxtd - 1;
-                    int q;                                                   // :221 python floor division
-                    if (magic && x >= 0 && x < 65536) q = (int)__umulhi((uint32_t)x, magic);
-                    else { q = x / vis_batch; if (x % vis_batch != 0 && x < 0) q--; }
-                    const double ndt = (double)(q * vis_period);
-                    v = arrv;                                                // :222 np.max([...])
-                    v = ndt > v ? ndt : v;
-                    v = now > v ? now : v;
+                    v = rearm_time((int)nxtd, arrv, now, vis_batch, vis_period);   // :221-222
                     ainfo()[a] = ai & ~A_INDEPOT;                            // :223-224 depot['members'].remove
                 }
             } else {
@@ -579,11 +585,27 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                     // (the task_update in between changed nothing about task k -- otherwise tu_what would say so -- so its
                     //  feasibility flag and finish time are the ones the step read)
                     if (lane == 0) R.nd()[a] = ((info & T_FEAS) && joined) ? tf_k : arrival + mwt;        // :229-238
+                } else if (au_mode == Rep::AU_ONE && !popped) {
+                    // ... and for a forced step to the depot (route exhausted / next task not visible yet: nothing was popped, so
+                    // the route position and the staged next action are the ones the step read; :212-226): the agent waits
+                    // there for good (nan) when the replay is not reactive, every visible task is feasible or its route is
+                    // exhausted; otherwise it is re-armed (:220-224)
+                    double v = __builtin_nan("");
+                    if (P.reactive && ninf_vis != 0 && !(len >= 0 && head >= len)) {
+                        if (len < 0) flags |= R_TYPE_ERROR;                  // :220 TypeError in the reference
+                        else {
+                            v = Rep::rearm_time((int)uni(nxt_v), arrival, now, P.vis_batch, P.vis_period);
+                            if (lane == 0) R.ainfo()[a] &= ~A_INDEPOT;       // :223-224 depot['members'].remove
+                        }
+                    }
+                    if (lane == 0 && !(flags & R_TYPE_ERROR)) R.nd()[a] = v;
                 } else
                     R.agent_update(now, mwt, P.reactive, visible, lane, flags, P.vis_batch, P.vis_period, au_mode, k, a,
                                    ninf_vis);                                // :576/:583/:587
                 WSYNC();
-                RPH(3);
+#ifdef DCM_REPLAY_PHASES   // agent_update after a step, by kind: 8 = written out inline, 9 = one agent (generic), 10 = task / full
+                if (au_mode == Rep::AU_ONE && action > 0) RPH(8); else if (au_mode == Rep::AU_ONE && !popped) RPH(9); else { RPH(10); RPH_COUNT(11); }
+#endif
                 if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
             }
             if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
@@ -706,10 +728,10 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     }
 #ifdef DCM_REPLAY_PHASES
     WSYNC();
-    if (time_start && lane < 8) {
+    if (time_start && lane < 12) {
         double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) if (lane == q) v = (double)rph_acc[q];
+        for (int q = 0; q < 12; q++) if (lane == q) v = (double)rph_acc[q];
         time_start[(size_t)e * T + lane] = v;
     }
 #endif

@@ -34,11 +34,12 @@ env.load_route_arrays(routes, route_len, member_cap=5)
 for _ in range(2):
     out = env.execute_routes(reactive, fields=("time_start",))
 torch.cuda.synchronize()
-ph = out["time_start"][:, :8].cpu().numpy()
+ph = out["time_start"][:, :12].cpu().numpy()
 steps = out["steps"].cpu().numpy().astype(np.float64)
-names = ["prologue", "task_update(full)", "task_update(one)", "agent_update", "agent_step", "check_finished"]
-tot = ph[:, :6].sum(1)
-print(f"B={B} {A}A/{T}T visibility={vis if reactive else 'static'}: {steps.mean():.0f} agent steps, {ph[:, 6].mean():.0f} events per env; "
+names = {0: "prologue", 1: "task_update(full)", 2: "task_update(one)", 3: "agent_update(event)", 4: "agent_step", 5: "check_finished",
+         8: "agent_update(inline)", 9: "agent_update(one)", 10: "agent_update(task/full)"}
+tot = ph[:, list(names)].sum(1)
+print(f"B={B} {A}A/{T}T visibility={vis if reactive else 'static'}: {steps.mean():.0f} agent steps, {ph[:, 6].mean():.0f} events and {ph[:, 11].mean():.0f} task/full agent updates after a step per env; "
       f"{tot.mean() / steps.mean():.0f} clocks per agent step")
-for i, n in enumerate(names):
+for i, n in names.items():
     print(f"  {n:20s} {ph[:, i].mean() / steps.mean():8.0f} clocks/step   {ph[:, i].sum() / tot.sum():6.1%}")
