@@ -267,10 +267,19 @@ struct Rep {
                 uint32_t due = 0;
 #pragma unroll
                 for (int c = 0; c < 8; c++) if (c < nc) { if (tb + c * WAVE + lane < T && now >= (double)wk[c]) due |= 1u << c; }
+                // the chunks with a due task: OR of the lanes' masks (DPP row shifts / broadcasts, no scalar loop over all eight)
+                uint32_t anyc = due;
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x111, 0xF, 0xF, false);   // row_shr:1
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x112, 0xF, 0xF, false);   // row_shr:2
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x114, 0xF, 0xF, false);   // row_shr:4
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x118, 0xF, 0xF, false);   // row_shr:8
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x142, 0xA, 0xF, false);   // row_bcast:15
+                anyc |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)anyc, 0x143, 0xC, 0xF, false);   // row_bcast:31
+                uint32_t todo = (uint32_t)__builtin_amdgcn_readlane((int)anyc, 63);
 #pragma nounroll
-                for (int c = 0; c < nc; c++) {
+                for (; todo; todo &= todo - 1) {
+                    const int c = __ffs((int)todo) - 1;
                     const bool act = (due >> c) & 1u;
-                    if (!__any(act)) continue;
                     uint32_t r = 0;
                     if (act) r = task_update_one(tb + c * WAVE + lane, now, mwt);
                     touched = touched || (r & 1u);
@@ -408,11 +417,11 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     uint32_t flags = 0;
     bool finished_flag = false, redo = true;
     int visible = 0, guard = 0, n_infeas = T;
-    int64_t steps = 0;
+    int steps = 0;
     const double mwt = P.mwt;                                                // :564
     // Guard (not in the reference): with reactive planning a depot agent whose next task id is beyond the hard
     // visibility cap of 100 re-decides at the same time forever (env/task_env.py:220-222,578-584); stop such envs.
-    const int64_t step_cap = 64 * (int64_t)(A + T) + 4096;
+    const int step_cap = 64 * (A + T) + 4096;
     WSYNC();
     // aw()[a] (scratch until the terminal metrics) holds the next preset action of agent a: staged once for everybody,
     // then refreshed only for the agent that pops its route (its entry is the only one that changes), with the global
@@ -491,14 +500,14 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                 const double nxt_v = R.aw()[a], sx = R.nx()[a], sy = R.ny()[a], px = R.ax()[a], py = R.ay()[a], td = R.tdist()[a],
                              amx = R.amax()[a];
                 uint32_t ai = R.ainfo()[a];
-                const int len = uni(len_v), head = uni(head_v);
+                const int len = len_v, head = head_v;
                 int action;
                 bool popped = false;
                 int32_t upcoming = 0;
                 double up_x = depot_x, up_y = depot_y;
                 if (len < 0 || head >= len) action = 0;                      // :573-577
                 else {
-                    const int nxt = (int)uni(nxt_v);                         // == my_routes[a][head]
+                    const int nxt = (int)nxt_v;                         // == my_routes[a][head]
                     if (P.reactive && nxt > visible) action = 0;             // :578-584
                     else {
                         action = nxt; popped = true;                         // :585 pop(0)
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                 uint32_t info = R.tinfo()[kk];
                 const int mine = lane < MR ? (int)R.mid()[lane * T + kk] : -1;
                 double slot_v = R.marr(lane < MR ? lane : 0, kk);              // lane j: arrival time of member slot j
-                const double tf_k = uni(R.tf()[kk]);
+                const double tf_k = R.tf()[kk];
                 const double dur_k = R.gtd[kk];              // (from HBM, needed only if the task becomes feasible in this step)
                 // target of a popped action = the coordinates staged for this agent (see `upcoming` below); a forced depot visit
                 // (route exhausted / next task not yet visible) leaves them in place for later
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                 const double d = dist2(px, py, tx_, ty_);
                 const double arrival = now + over_velocity(d);                      // :315,:318
                 const double tdist_new = td + d;                                    // :317
-                ai = uni(ai) & ~A_MEMBER; info = uni(info);
+                ai = ai & ~A_MEMBER;
                 int pos = -1;
                 bool fresh = false;
                 if (action == 0) ai |= A_INDEPOT;                            // :321-322
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
                     if (P.reactive && ninf_vis != 0 && !(len >= 0 && head >= len)) {
                         if (len < 0) flags |= R_TYPE_ERROR;                  // :220 TypeError in the reference
                         else {
-                            v = Rep::rearm_time((int)uni(nxt_v), arrival, now, P.vis_batch, P.vis_period);
+                            v = Rep::rearm_time((int)nxt_v, arrival, now, P.vis_batch, P.vis_period);
                             if (lane == 0) R.ainfo()[a] &= ~A_INDEPOT;       // :223-224 depot['members'].remove
                         }
                     }
