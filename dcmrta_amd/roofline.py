@@ -64,7 +64,9 @@ def issue_roofline(c, units_per_step, step_s, unit="decision"):
     arithmetic and conversions; the remaining instructions (moves, selects, compares, integer and cross-lane work) are priced
     at the 32-bit rate for `frac` (an estimate that can only be low: part of them are 4-clock instructions) and at the 64-bit
     rate for `frac_hi` (every VALU instruction at 4.25 clocks -- the upper bound; round 2's figure).  Both are fractions of
-    1024 SIMDs x 2.4 GHz.  `salu_issue_frac`: scalar-unit issue slots used, 256 CUs x 2.4 GHz / 1.07 clocks per instruction."""
+    1024 SIMDs x 2.4 GHz.  `salu_issue_frac`: scalar-unit issue slots used, 256 CUs x 2.4 GHz / 1.07 clocks per instruction; when
+    it exceeds `frac_hi` the scalar unit is the binding resource: `bound` = "salu_issue" and `achieved` / `peak` / `frac` describe
+    it (the VALU figures move to `valu_issue_frac` / `valu_issue_frac_hi`)."""
     n_valu = c[f"SQ_INSTS_VALU_per_{unit}"]
     have_classes = all(f"{k}_per_{unit}" in c for k in F64_CLASS_COUNTERS)
     n64 = sum(c[f"{k}_per_{unit}"] for k in F64_CLASS_COUNTERS) if have_classes else 0.0
@@ -80,8 +82,17 @@ def issue_roofline(c, units_per_step, step_s, unit="decision"):
                                "frac_hi prices every VALU instruction at 4.25"}}
     n_salu = c.get(f"SQ_INSTS_SALU_per_{unit}")
     if n_salu is not None:
-        out["salu_issue_frac"] = n_salu * CLOCKS_SALU_PER_CU * per_s / (N_CU * PEAK_CLOCK_HZ)
+        salu = n_salu * CLOCKS_SALU_PER_CU * per_s / (N_CU * PEAK_CLOCK_HZ)
+        out["salu_issue_frac"] = salu
         out["salu_insts_per_" + unit] = n_salu
+        if salu > out["frac_hi"]:
+            # the CU's single scalar unit is busier than the four VALU pipes can be even at the upper price (route replay since
+            # its state left LDS for 14 resident waves per CU): that is the binding resource, and `frac` describes it; the VALU
+            # figures stay on record next to it
+            out.update({"bound": "salu_issue", "valu_issue_frac": out["frac"], "valu_issue_frac_hi": out["frac_hi"],
+                        "achieved": n_salu * CLOCKS_SALU_PER_CU * per_s / 1e9, "peak": N_CU * PEAK_CLOCK_HZ / 1e9,
+                        "unit": "G scalar-unit clocks/s (one scalar unit per CU, 1.07 clocks per instruction)", "frac": salu})
+            del out["frac_hi"]
     if f"SQ_THREAD_CYCLES_VALU_per_{unit}" in c and f"SQ_ACTIVE_INST_VALU_per_{unit}" in c:
         out["lane_util"] = c[f"SQ_THREAD_CYCLES_VALU_per_{unit}"] / (64.0 * c[f"SQ_ACTIVE_INST_VALU_per_{unit}"])
     wave = c.get(f"SQ_WAVE_CYCLES_per_{unit}")

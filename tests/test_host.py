@@ -272,3 +272,8 @@ def test_issue_roofline_pricing():
     assert len({v.get("build_id") for v in allc.values()}) == 1 and all(v.get("build_id") for v in allc.values())
     for key in ("k_rollout_random:20A50T", "k_rollout_random:50A200T", "k_replay:100A500T", "k_step:4096x20A50T", "k_step:65536x20A50T"):
         assert key in allc, key                                         # every BASELINE config's dominant kernel has a profile
+    # a kernel whose scalar-unit time exceeds even the upper VALU price is bound by the CU's one scalar unit
+    c3 = dict(c, **{"SQ_INSTS_SALU_per_decision": 400.0})
+    r3 = R.issue_roofline(c3, 1e6, 1e-3)
+    assert r3["bound"] == "salu_issue" and abs(r3["frac"] - 400 * 1.07 * 1e9 / (256 * 2.4e9)) < 1e-12 and r3["frac"] == r3["salu_issue_frac"]
+    assert abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-12 and r3["valu_issue_frac"] <= r3["valu_issue_frac_hi"] < r3["frac"]
