@@ -234,9 +234,7 @@ int dcm_distance(const double *ax, const double *ay, const double *bx, const dou
 /* pre_set_route (env/task_env.py:595-599) for every agent of every env:
  * routes[B,A,route_cap] i32 actions in visiting order (0 = depot, k = task k-1; what baselines/CTAS-D.py:41-45 passes),
  * route_len[B,A] i32 (-1 = pre_set_route stays None, 0 = empty list).  member_cap (1..32) sizes the per-task member
- * slots of replay mode, where a task may collect more agents than it requires. Arrays are copied; the call also allocates
- * the handle's replay scratch in device memory (8 T (member_cap + 1) + 16 A + 4 T bytes per env: member arrival times,
- * time_finish, wake-up times, travel distance and latest arrival, which the replay kernel keeps in HBM instead of LDS). */
+ * slots of replay mode, where a task may collect more agents than it requires. Arrays are copied. */
 int dcm_load_routes(dcm_env *env, const int32_t *routes, const int32_t *route_len, int32_t route_cap,
                     int32_t member_cap, void *stream);
 
