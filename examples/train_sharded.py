@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -26,11 +27,20 @@ from dcmrta_amd.dist_runner import ShardedRunner  # noqa: E402
 from dcmrta_amd.policy import AttentionNet  # noqa: E402
 
 
-def reinforce_loss_sum(net, res):
-    """driver.py:175-180 on one rank's decisions, summed (the mean is taken over all ranks afterwards)."""
+def reinforce_backward(net, res, scale=1.0, minibatch=8192):
+    """driver.py:175-182 on a set of decisions: back-propagates scale * sum_i -logp_i(action_i) * advantage_i.  The decisions are
+    fed through the net `minibatch` at a time and the gradients accumulate, which is the same sum without holding the activations
+    of a whole round (5e5 decisions at 4096 envs) at once -- the reference's learner takes 1024 decisions per step for the same
+    reason (driver.py:144-147, BATCH_SIZE).  Returns (loss sum as a float, number of decisions)."""
     agents, tasks, action, mask, adv = res[0], res[1], res[2], res[3], res[6]
-    logp = net(tasks, agents, mask)
-    return -(torch.gather(logp, 1, action) * adv.detach()).sum(), agents.shape[0]
+    n, total = agents.shape[0], 0.0
+    for lo in range(0, n, minibatch):
+        hi = min(n, lo + minibatch)
+        logp = net(tasks[lo:hi], agents[lo:hi], mask[lo:hi])
+        loss = -(torch.gather(logp, 1, action[lo:hi]) * adv[lo:hi].detach()).sum()
+        (loss * scale).backward()
+        total += float(loss.detach())
+    return total, n
 
 
 def main():
@@ -42,11 +52,14 @@ def main():
     ap.add_argument("--tasks", type=int, nargs=2, default=(20, 50))
     ap.add_argument("--learner", choices=("all_reduce", "rank0"), default="all_reduce")
     ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--minibatch", type=int, default=8192, help="decisions per forward / backward of the learner (gradients accumulate)")
+    ap.add_argument("--precision", choices=("fp32", "fp16", "bf16"), default="fp32", help="arithmetic of the ROLLOUT policy (the learner is fp32)")
     ap.add_argument("--dump", default=None, help="directory for per-rank result files (tests)")
     args = ap.parse_args()
     ctx = DistContext.from_env()
     torch.manual_seed(1234 + ctx.rank)       # deliberately different initial weights per rank: broadcast_weights must fix that
-    sr = ShardedRunner(args.total_envs, ctx=ctx, net_factory=lambda: AttentionNet(6, 5, args.embedding), base_seed=7)
+    sr = ShardedRunner(args.total_envs, ctx=ctx, net_factory=lambda: AttentionNet(6, 5, args.embedding), base_seed=7,
+                       rollout_precision=args.precision, buckets=(1.0, 0.5, 0.25, 0.125) if args.total_envs >= 1024 else None)
     sr.runner.keep_greedy_record = bool(args.dump)
     sr.broadcast_weights(src=0)
     net = sr.runner.localNetwork
@@ -60,7 +73,10 @@ def main():
         if ctx.active:
             dist.broadcast(shape, src=0)
         A, T = int(shape[0]), int(shape[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         res, metrics, info = sr.job(rnd, A, T)
+        torch.cuda.synchronize()
         if args.dump:
             rec = sr.runner._slot(A, T)["graphs"][(id(sr.runner._rollout_net()), "sample", True)].rec
             n = sr.runner.last["n_steps"]
@@ -68,17 +84,17 @@ def main():
                      returns=info["returns"].cpu().numpy(), summary=sr.runner.last["summary"].cpu().numpy(),
                      greedy_summary=sr.runner.last["greedy_summary"].cpu().numpy(),
                      **{k: v[:n].cpu().numpy() for k, v in rec.items()})
+        t_roll = time.perf_counter() - t0
         opt.zero_grad()
         if args.learner == "all_reduce":
-            loss, n_loc = reinforce_loss_sum(net, res)
-            loss.backward()
+            loss, n_loc = reinforce_backward(net, res, minibatch=args.minibatch)
             n_all = sr.all_reduce_gradients(net, n_loc)
         else:
             gathered = sr.gather_experience(res, dst=0)
             n_all = 0
             if ctx.rank == 0:
-                loss, n_all = reinforce_loss_sum(net, gathered)
-                (loss / n_all).backward()
+                n_all = gathered[0].shape[0]
+                loss, _ = reinforce_backward(net, gathered, scale=1.0 / n_all, minibatch=args.minibatch)
         if args.learner == "all_reduce" or ctx.rank == 0:
             torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1000.0)       # driver.py:185
             opt.step()
@@ -86,8 +102,11 @@ def main():
             sr.broadcast_weights(src=0)
         else:
             sr.runner.set_weights(net.state_dict())                                  # refresh a low-precision shadow, if any
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
         log.append(dict(round=rnd, A=A, T=T, decisions=n_all, makespan=metrics["makespan"], success_rate=metrics["success_rate"],
-                        weights_checksum=sr.weights_checksum()))
+                        weights_checksum=sr.weights_checksum(), rollout_seconds=round(t_roll, 4), learner_seconds=round(t_all - t_roll, 4),
+                        decisions_per_s=round(n_all / t_all, 1)))
     if args.dump:
         with open(os.path.join(args.dump, f"log_rank{ctx.rank}.json"), "w") as f:
             json.dump(log, f)
