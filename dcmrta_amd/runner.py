@@ -38,14 +38,16 @@ class EnvError(RuntimeError):
 
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
-                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets=None, episode_stride=None,
+                 rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets="auto", episode_stride=None,
                  env_offset=0, strict_mask=False, twin_rollout=False):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
         steps (default 6 (A + T) + 64, ~3x the longest episode seen at the reference's constants).  buckets: e.g.
         (1.0, 0.5, 0.25) -- the policy runs only on the envs still active once half / three quarters of the episodes are
-        over (GraphedRollout compaction; worthwhile when the forward is much more expensive than the env step)."""
+        over (GraphedRollout compaction; worthwhile when the forward is much more expensive than the env step).  "auto" (default):
+        (1.0, 0.5, 0.25, 0.125) from 1024 envs on -- a 4096-env job of the attention policy takes 1.8 instead of 2.2 s -- none
+        below (the loop is launch-bound there and three more graphs per shape and rollout kind only cost capture time)."""
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
@@ -69,6 +71,10 @@ class BatchedRunner:
         self.max_steps = None if max_steps is None else int(max_steps)
         self.gamma = float(gamma)            # GAMMA, parameters.py:6 (1 in the reference)
         self.check_every, self.use_graph = int(check_every), bool(use_graph)
+        if isinstance(buckets, str):
+            if buckets != "auto":
+                raise ValueError('buckets: "auto", None or a tuple of fractions')
+            buckets = (1.0, 0.5, 0.25, 0.125) if self.B >= 1024 else None
         self.buckets = tuple(buckets) if buckets else None
         if net_factory is None:
             from .policy import AttentionNet

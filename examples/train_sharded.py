@@ -59,7 +59,7 @@ def main():
     ctx = DistContext.from_env()
     torch.manual_seed(1234 + ctx.rank)       # deliberately different initial weights per rank: broadcast_weights must fix that
     sr = ShardedRunner(args.total_envs, ctx=ctx, net_factory=lambda: AttentionNet(6, 5, args.embedding), base_seed=7,
-                       rollout_precision=args.precision, buckets=(1.0, 0.5, 0.25, 0.125) if args.total_envs >= 1024 else None)
+                       rollout_precision=args.precision)
     sr.runner.keep_greedy_record = bool(args.dump)
     sr.broadcast_weights(src=0)
     net = sr.runner.localNetwork
