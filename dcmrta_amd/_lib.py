@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCMRTA_HIP_LIB") or os.path.join(_HERE, "libdcmrta_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FOLLOWER_COLS = 4
 MAX_MEMBERS = 5
 MAX_AGENTS = 128
@@ -62,6 +62,7 @@ SIGNATURES = {
     "dcm_load_routes": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dcm_execute_routes": (C.c_int, [_vp, _i32] + [_vp] * 11),
     "dcm_set_visibility": (C.c_int, [_vp, _i32, _i32, _i32, _i32]),
+    "dcm_set_replay_placement": (C.c_int, [_vp, _i32]),
     "dcm_set_return_log": (C.c_int, [_vp, _vp, _i32]),
 }
 

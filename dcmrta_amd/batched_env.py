@@ -320,6 +320,12 @@ class BatchedTaskEnv:
         check(self._lib.dcm_set_visibility(self._h, int(initial), int(batch), int(period), int(cap)))
         return self
 
+    def set_replay_placement(self, placement="auto"):
+        """Where execute_routes keeps the replay state that is off the event loop's critical path: "auto" (LDS for batches of at
+        most four envs per CU, else HBM), "lds" or "hbm" (dcm_set_replay_placement).  Results do not depend on it."""
+        check(self._lib.dcm_set_replay_placement(self._h, {"auto": 0, "lds": 1, "hbm": 2}[placement]))
+        return self
+
     def execute_routes(self, reactive=False, fields=None):
         """execute_by_route + get_episode_reward for every env; returns a dict of device tensors.
         fields: which of the optional per-task / per-agent arrays to produce (default: all; () = steps, flags, summary only)."""

@@ -357,6 +357,7 @@ struct dcm_env {
     int32_t* route_len = nullptr;    // [B][A], -1 = pre_set_route is None
     int32_t route_cap = 0, member_cap = 0;
     double* rmarr = nullptr;         // replay scratch (dcm_load_routes): per env member arrival times [T][member_cap], time_finish [T], travel_dist and max arrival [A]
+    int32_t replay_placement = 0;    // dcm_set_replay_placement: 0 auto, 1 replay scratch in LDS, 2 in HBM
     int32_t vis[4] = {20, 20, 10, 100};  // dynamic-arrival schedule: initial, batch, period, cap (env/task_env.py:567,:221)
     dcm::RouteLog log{nullptr, nullptr, nullptr, 0};   // dcm_set_route_log
     double* retlog = nullptr;        // dcm_set_return_log: [B][retcap] ring of episode returns

@@ -42,6 +42,9 @@ struct RLay {
     __device__ uint32_t tinfo() const { return tb(); }                     // u32[T]
     __device__ uint32_t mid() const { return tinfo() + 4 * T; }            // u8[MR][T]
     __device__ uint32_t tsc() const { return 48 * A >= 8 * T ? 0u : (uint32_t)((mid() + MR * T + 7) & ~7); }   // f64[T], terminal only
+    // the "replay scratch" block (member arrivals, time_finish, travel_dist, max arrival, wake-up times) when it is kept in LDS
+    // (grids of at most one wave per SIMD, see replay_lds_bytes): behind everything else
+    __device__ uint32_t state() const { return (uint32_t)((mid() + MR * T + 7) & ~7) + (48 * A >= 8 * T ? 0u : 8u * (uint32_t)T); }
 };
 // What the event loop does not touch, or touches off its critical path, stays out of LDS.  In the HBM record: the read-only
 // instance arrays (task x, y, duration: a task's duration is read once, when it becomes feasible; the coordinates of an agent's
@@ -54,12 +57,15 @@ struct RLay {
 // and served in order, so the wave sees its own stores (wavefront-scope fences need no cache action).
 // 100A/500T with member_cap 5: 13.7 KB of LDS per env = ELEVEN resident waves per CU (rounds 1-2: two, with 74 KB; round 3 at
 // first three, then four with 39.3 KB -- one wave per SIMD, every instruction and LDS round trip at full latency).
-__host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR) {
-    const uint32_t loop = (uint32_t)(72 * A + 4 * T + MR * T);
-    return align16(48 * A >= 8 * T ? loop : ((loop + 7u) & ~7u) + 8u * (uint32_t)T);
-}
 __host__ __device__ inline size_t replay_scratch_bytes(int A, int T, int MR) {
     return (size_t)8 * T * MR + (size_t)8 * T + (size_t)16 * A + (((size_t)4 * T + 7) & ~(size_t)7);
+}
+// state_in_lds: the replay scratch block sits behind the LDS layout instead of in HBM.  With at most four envs per CU (the 8-GPU
+// shard of BASELINE config 5: 1024 envs per GPU) every env is resident at once whatever it costs in LDS, there is nothing to
+// overlap with, and what counts is the latency of one wave's chain: 35.3 KB per env at 100A/500T, all accesses LDS round trips.
+__host__ __device__ inline uint32_t replay_lds_bytes(int A, int T, int MR, bool state_in_lds = false) {
+    const uint32_t loop = (((uint32_t)(72 * A + 4 * T + MR * T) + 7u) & ~7u) + (48 * A >= 8 * T ? 0u : 8u * (uint32_t)T);
+    return align16(loop + (state_in_lds ? (uint32_t)replay_scratch_bytes(A, T, MR) : 0u));
 }
 
 struct RP {
@@ -378,8 +384,8 @@ struct Rep {
 };
 
 // <CA, CT, CMR> = the batch's agents / tasks / member slots as compile-time constants (every LDS offset and loop bound folds), or
-// <0, 0, 0> = read from the arguments.
-template <int CA, int CT, int CMR>
+// <0, 0, 0> = read from the arguments.  SLDS: the replay scratch block in LDS instead of HBM (see replay_lds_bytes).
+template <int CA, int CT, int CMR, bool SLDS>
 __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT, int MR_, RP P, const unsigned char* state,
                                                 const int32_t* routes, const int32_t* route_len, int route_cap,
                                                 double* summary, int64_t* steps_out, uint32_t* flags_out,
@@ -393,7 +399,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
           (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
           (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort()),
-          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), (double*)((unsigned char*)member_arrivals + (size_t)e * replay_scratch_bytes(A, T, MR))};
+          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), SLDS ? (double*)(smem + RLay{A, T, MR}.state())
+               : (double*)((unsigned char*)member_arrivals + (size_t)e * replay_scratch_bytes(A, T, MR))};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
     const int32_t* my_routes = routes + (size_t)e * A * route_cap;
@@ -779,6 +786,13 @@ int dcm_set_visibility(dcm_env* env, int32_t initial, int32_t batch, int32_t per
     return DCM_OK;
 }
 
+int dcm_set_replay_placement(dcm_env* env, int32_t placement) {
+    CHECK_HANDLE(env);
+    if (placement < 0 || placement > 2) return fail(DCM_ERR_INVALID, "dcm_set_replay_placement: 0 = auto, 1 = LDS, 2 = HBM");
+    env->replay_placement = placement;
+    return DCM_OK;
+}
+
 int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint32_t* flags_out, uint8_t* finished,
                        double* time_start, double* time_finish, double* task_wait, int32_t* n_members,
                        double* agent_wait, double* travel_dist, uint8_t* returned, void* stream) {
@@ -786,19 +800,30 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_instances first");
     if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
     if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");
-    const uint32_t lds = replay_lds_bytes(env->A, env->T, env->member_cap);
+    // Where the replay scratch block lives: in LDS when the whole batch is resident with at most one wave per SIMD anyway (<= 4
+    // envs per CU) and it fits a quarter of the CU's LDS, else in HBM (14 instead of 4 resident waves per CU at 100A/500T).
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, env->p.device));
+    const uint32_t lds_in = replay_lds_bytes(env->A, env->T, env->member_cap, true);
+    bool slds = lds_in <= 40u * 1024u && env->p.n_envs <= 4 * cus;
+    if (env->replay_placement == 1) slds = lds_in <= 160u * 1024u;
+    if (env->replay_placement == 2) slds = false;
+    const uint32_t lds = slds ? lds_in : replay_lds_bytes(env->A, env->T, env->member_cap, false);
 
     RP P{100.0, 200.0, reactive ? 1 : 0, env->vis[0], env->vis[1], env->vis[2], env->vis[3]};  // env/task_env.py:564-565,567
-#define REPLAY(CA, CT, CMR)                                                                                                  \
+#define REPLAY(CA, CT, CMR, SL)                                                                                              \
     do {                                                                                                                    \
-        (void)hipFuncSetAttribute((const void*)k_replay<CA, CT, CMR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_replay<CA, CT, CMR>), GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T,  \
+        (void)hipFuncSetAttribute((const void*)k_replay<CA, CT, CMR, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_replay<CA, CT, CMR, SL>), GRID(env), lds, (hipStream_t)stream, env->A, env->T, env->L.A, env->L.T,  \
                            env->member_cap, P, env->state, env->routes, env->route_len, env->route_cap, env->summary,      \
                            steps_out, flags_out, finished, time_start, time_finish, task_wait, n_members, agent_wait,       \
                            travel_dist, returned, env->gscratch, env->rmarr);                                              \
     } while (0)
-    if (env->A == 100 && env->T == 500 && env->member_cap == 5) REPLAY(100, 500, 5);   // BASELINE config 5
-    else REPLAY(0, 0, 0);
+    const bool base5 = env->A == 100 && env->T == 500 && env->member_cap == 5;   // BASELINE config 5
+    if (base5 && slds) REPLAY(100, 500, 5, true);
+    else if (base5) REPLAY(100, 500, 5, false);
+    else if (slds) REPLAY(0, 0, 0, true);
+    else REPLAY(0, 0, 0, false);
 #undef REPLAY
     LAUNCH_OK();
     return DCM_OK;

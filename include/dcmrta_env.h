@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DCM_ABI_VERSION 3 /* v3: dcm_build_id, dcm_set_visibility, dcm_load_instances validates req on the device */
+#define DCM_ABI_VERSION 4 /* v3: dcm_build_id, dcm_set_visibility, dcm_load_instances validates req on the device; v4: dcm_set_replay_placement */
 
 typedef struct dcm_env dcm_env; /* opaque */
 
@@ -246,6 +246,13 @@ int dcm_load_routes(dcm_env *env, const int32_t *routes, const int32_t *route_le
  *   visible_length = int(clip(now // period * batch + initial, initial, cap)),  re-arm (next - 1) // batch * period.
  * Needs initial >= 0, batch >= 1, period >= 1, cap >= initial.  Host-side setter; takes effect at the next dcm_execute_routes. */
 int dcm_set_visibility(dcm_env *env, int32_t initial, int32_t batch, int32_t period, int32_t cap);
+
+/* Where dcm_execute_routes keeps the part of the replay state that is off the event loop's critical path (member arrival
+ * times, time_finish, wake-up times, travel distance, latest arrival; "replay scratch", allocated by dcm_load_routes:
+ * 8 T (member_cap + 1) + 16 A + 4 T bytes per env).  0 = auto (default): in LDS when the batch has at most four envs per
+ * CU -- every env is resident at once anyway and one wave's latency is what counts -- else in HBM, which leaves 14 instead
+ * of 4 waves per CU resident at 100A/500T; 1 = LDS, 2 = HBM (for tests / measurements).  Results do not depend on it. */
+int dcm_set_replay_placement(dcm_env *env, int32_t placement);
 
 /* execute_by_route (env/task_env.py:562-593; max_waiting_time 100, cut-off 200) followed by get_episode_reward
  * (:420-425), whole episode in one launch.  reactive != 0 enables dynamic task visibility (:566-567,:578-584 and the

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the route-replay kernel against the oracle (developer tool, GPU box)."""
+"""Randomised parity sweep of the route-replay kernel against the oracle (developer tool, GPU box).
+
+    python tools/sweep_replay.py [shapes] [seed] [auto|lds|hbm]     (where the kernel keeps its replay scratch, dcm_set_replay_placement)"""
 import os
 import sys
 import time
@@ -15,6 +17,7 @@ from dcmrta_amd.instances import generate_batch  # noqa: E402
 n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
+placement = sys.argv[3] if len(sys.argv) > 3 else "auto"
 KEYS = ("finished", "time_start", "time_finish", "task_wait", "n_members", "travel_dist", "returned", "agent_wait")
 bad = checked = trunc = terr = 0
 t0 = time.time()
@@ -46,6 +49,7 @@ for it in range(n_shapes):
         routes.append(rr)
     env = BatchedTaskEnv(B, A, T).load_instances(**inst)
     env.load_routes(routes, member_cap=12)
+    env.set_replay_placement(placement)
     out = env.execute_routes(reactive=reactive)
     flags = out["flags"].cpu().numpy()
     for b in range(B):
