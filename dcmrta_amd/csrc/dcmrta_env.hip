@@ -77,7 +77,11 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 //                    driver.py:114-115 draws a new shape every round) -- keeps constant LDS offsets and unrolled lane-chunk
 //                    loops; only the loop guards read the sizes
 //   <0, 0, false>    anything else: runtime sizes and a runtime layout Lay{pA,pT}
-template <int CA, int CT, bool RS>
+// MG (exact multi-chunk shapes, persistent kernel only): the member arrival times f64[M][T] -- 43 % of a 50A/200T LDS image -- are
+// not copied into LDS at all: the kernel works on the marr section of the env's own HBM record (one wave owns the record; a
+// wave's global accesses are issued and served in order, so it sees its own stores, and the section is read only at the head of
+// task_update's chain and by the terminal metrics).  The sections behind it move up by MSH bytes in the LDS image.
+template <int CA, int CT, bool RS, bool MG = false>
 struct Sim {
     static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
     static constexpr int NTC = CT ? (CT + 63) / 64 : 0;       // task lane chunks (0 = runtime)
@@ -86,6 +90,8 @@ struct Sim {
     int pA, pT;           // record layout dims (read by the <0,0> instantiation only)
     unsigned char* base;  // record base (LDS in the env kernels)
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
+    double* gm = nullptr; // MG: the marr section of this env's HBM record
+    static constexpr uint32_t MSH = MG ? 40u * (uint32_t)CT : 0u;   // = Lay::mids() - Lay::marr()
     // Exact multi-chunk shapes (50A/200T, 100A/500T): the task coordinates -- read-only instance data that only the task's own
     // lane and, for the chosen task, the whole wave ever read -- live in two registers per lane chunk (struct XY, owned by the
     // kernel and handed to observe / apply_and_advance) instead of 16 bytes per task of LDS.  The LDS image of a 50A/200T env
@@ -93,6 +99,7 @@ struct Sim {
     // k_step<50,200> at 16 384 envs -4 %.  (For the one-chunk layouts the same change was measured SLOWER: their kernels are
     // limited by registers, not LDS.)
     static constexpr bool IRB = (CT > WAVE) && !RS;
+    static_assert(!MG || ((CT > WAVE) && !RS), "MG needs an exact multi-chunk shape");
     struct XY { double x[IRB ? NTC : 1], y[IRB ? NTC : 1]; };
     // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
     // BASELINE batch be resident); every other kernel trades it for more resident workgroups
@@ -135,17 +142,17 @@ struct Sim {
     __device__ __forceinline__ uint32_t* ainfo() const { return (uint32_t*)(base + L().ainfo()); }
     __device__ __forceinline__ double* ts() const { return (double*)(base + L().ts()); }
     __device__ __forceinline__ double* tf() const { return (double*)(base + L().tf()); }
-    __device__ __forceinline__ double* marr() const { return (double*)(base + L().marr()); }
-    __device__ __forceinline__ uint64_t* mids() const { return (uint64_t*)(base + L().mids()); }
-    __device__ __forceinline__ uint32_t* tinfo() const { return (uint32_t*)(base + L().tinfo()); }
-    __device__ __forceinline__ uint32_t* tnab() const { return (uint32_t*)(base + L().tnab()); }
+    __device__ __forceinline__ double* marr() const { if constexpr (MG) return gm; else return (double*)(base + L().marr()); }
+    __device__ __forceinline__ uint64_t* mids() const { return (uint64_t*)(base + L().mids() - MSH); }
+    __device__ __forceinline__ uint32_t* tinfo() const { return (uint32_t*)(base + L().tinfo() - MSH); }
+    __device__ __forceinline__ uint32_t* tnab() const { return (uint32_t*)(base + L().tnab() - MSH); }
     __device__ __forceinline__ double* tx() const { return (double*)(base + L().tx()); }
     __device__ __forceinline__ double* ty() const { return (double*)(base + L().ty()); }
-    __device__ __forceinline__ double* tdur() const { return (double*)(base + (IRB ? L().tx() : L().tdur())); }   // IRB image: no x / y sections
-    __device__ __forceinline__ uint32_t aux_off() const { return IRB ? L().tx() + 8u * (uint32_t)PT() : L().aux(); }
+    __device__ __forceinline__ double* tdur() const { return (double*)(base + (IRB ? L().tx() : L().tdur()) - MSH); }   // IRB image: no x / y sections
+    __device__ __forceinline__ uint32_t aux_off() const { return (IRB ? L().tx() + 8u * (uint32_t)PT() : L().aux()) - MSH; }
     // (+ 4 T bytes of wake-up times, see task_update, for the layouts with more than one lane chunk of tasks)
     static __host__ __device__ constexpr uint32_t lds_image_bytes(Lay l) {
-        return (IRB ? l.tx() + 8u * (uint32_t)l.T + 48u : l.lds_rec()) + ((CT == 0 || CT > WAVE) ? align16(4u * (uint32_t)l.T) : 0u);
+        return (IRB ? l.tx() + 8u * (uint32_t)l.T + 48u : l.lds_rec()) - MSH + ((CT == 0 || CT > WAVE) ? align16(4u * (uint32_t)l.T) : 0u);
     }
     // coordinates of task k (wave-uniform k): lane k & 63 of chunk k >> 6 holds them, or the LDS image does
     __device__ __forceinline__ void task_xy(int k, const XY& xy, double& x, double& y) const {
@@ -192,7 +199,12 @@ struct Sim {
                 xy.x[c] = ((const double*)(rec + l.tx()))[t];
                 xy.y[c] = ((const double*)(rec + l.ty()))[t];
             }
-            if constexpr (ALL) {       // mutable part, then the durations right behind it (the x / y sections are skipped)
+            if constexpr (MG) {        // ... and the member arrival times stay where they are
+                static_assert(l.marr() % 16 == 0 && l.mids() % 16 == 0 && MSH % 16 == 0, "16-byte copies");
+                copy16_in(base, rec, l.marr(), lane);
+                copy16_in(base + l.mids() - MSH, rec + l.mids(), l.mut_bytes() - l.mids(), lane);
+                copy16_in(base + l.tx() - MSH, rec + l.tdur(), align16(8 * CT), lane);
+            } else if constexpr (ALL) {       // mutable part, then the durations right behind it (the x / y sections are skipped)
                 copy16_in_all<l.mut_bytes(), NT>(base, rec, lane);
                 copy16_in_all<align16(8 * CT), NT>(base + l.tx(), rec + l.tdur(), lane);
             } else {
@@ -201,6 +213,15 @@ struct Sim {
             }
         } else if constexpr (CA != 0 && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
         else copy16_in(base, rec, L().rec_bytes(), lane);
+    }
+
+    // mutable part of the LDS image -> HBM record
+    __device__ __forceinline__ void store_record(unsigned char* rec, int lane) const {
+        const Lay l = L();
+        if constexpr (MG) {
+            copy16(rec, base, l.marr(), lane);
+            copy16(rec + l.mids(), base + l.mids() - MSH, l.mut_bytes() - l.mids(), lane);
+        } else copy16(rec, base, l.mut_bytes(), lane);
     }
 
     // optional return log (dcm_set_return_log): this env's ring of `cap` episode returns; pointer kept in the LDS image
@@ -1310,7 +1331,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
 // this launch; when the budget runs out the env stays at the decision point it has reached (a later call -- dcm_rollout_random,
 // dcm_observe or dcm_step -- carries on from it) and the observation buffers hold what the last decision TAKEN saw.
 template <int CA, int CT, bool RS>
-__global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
+__global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
                                                         const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
@@ -1318,13 +1339,15 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
-    using AMask = typename Sim<CA, CT, RS>::AMask;
+    using SimT = Sim<CA, CT, RS, (CT > WAVE) && !RS>;   // member arrival times in the HBM record (MG) for the exact multi-chunk shapes
+    SimT S{eA, eT, PA, PT, smem, nullptr};
+    using AMask = typename SimT::AMask;
     const Lay L = S.L();
-    S.scr = Sim<CA, CT, RS>::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
+    S.scr = SimT::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    typename Sim<CA, CT, RS>::XY xy;
+    S.gm = (double*)(rec + L.marr());
+    typename SimT::XY xy;
     S.template load_record<true, false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
@@ -1388,7 +1411,7 @@ __global__ __launch_bounds__(WAVE) void k_rollout_random(int A, int T, int PA, i
     WSYNC();
     store_hdr(h, lane);
     WSYNC();
-    copy16(rec, smem, L.mut_bytes(), lane);
+    S.store_record(rec, lane);
 }
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
@@ -1738,7 +1761,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
 #define CALL(CA, CT, RS)                                                                                              \
     hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
-                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
+                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS, ((CT) > WAVE) && !(RS)>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
     DISPATCH_ENV(env, CALL);
