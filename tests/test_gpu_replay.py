@@ -60,9 +60,10 @@ from dcmrta_amd.instances import synthetic_routes  # noqa: E402
 
 @pytest.mark.parametrize("A,T,reactive,cap", [(100, 500, False, 8), (100, 500, True, 8), (100, 100, True, 8), (50, 200, True, 8),
                                               (13, 37, False, 8),
-                                              # bench.py --config 5's setting: 5 member slots = four resident waves per CU
+                                              # bench.py --config 5's setting: 5 member slots
                                               (100, 500, False, 5), (100, 500, True, 5)])
-def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive, cap):
+@pytest.mark.parametrize("placement", ["lds", "hbm"])   # where the kernel keeps its replay scratch (auto: by batch size)
+def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive, cap, placement):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
     B = 3
@@ -71,6 +72,7 @@ def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive, cap):
     env = BatchedTaskEnv(B, A, T, device=gpu_device)
     env.load_instances(**inst)
     env.load_routes(rl, member_cap=cap)
+    env.set_replay_placement(placement)
     out = env.execute_routes(reactive=reactive)
     flags = out["flags"].cpu().numpy()
     assert not (flags & 0x78).any()
