@@ -1330,6 +1330,10 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
 // budget (per env: budget_in[e] if given, else budget_all; < 0 = unlimited): an env takes at most that many decisions in
 // this launch; when the budget runs out the env stays at the decision point it has reached (a later call -- dcm_rollout_random,
 // dcm_observe or dcm_step -- carries on from it) and the observation buffers hold what the last decision TAKEN saw.
+// __launch_bounds__(64, 3): at least three waves per SIMD.  The one-chunk shapes need 111 VGPRs anyway (four waves per SIMD); the
+// 50A/200T instantiation wants 176 -- two waves per SIMD although its LDS image (10.9 KB with the member arrival times left in
+// the HBM record) would let twelve workgroups share a CU -- and with 168 (five spilled) it runs three: 8.65 -> 6.90 ms per
+// 8192-env launch.  Four (128 VGPRs, 47 spilled) measured slower again (7.15 ms).
 template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,

@@ -6,14 +6,17 @@
 // (capped at 100) when reactive.  This is the deterministic known-answer path of the reference (the
 // CTAS-D routes reproduce testSet_20A_50T_CONDET/metrics/metrics.csv:2) and BASELINE config 5.
 //
-// One wavefront per env, the whole episode in one launch, the state the event loop works on in LDS (instance
-// fields are read from the env record that dcm_load_instances filled).  Unlike RL mode a task may collect more
-// members than its requirement, so member slots are sized by `member_cap` (<= 32) and walked with runtime loops.
+// One wavefront per env, the whole episode in one launch.  LDS holds what the event loop reads on its critical path (agent
+// arrays, task status words, member ids); the member arrival times, time_finish, the wake-up times and two per-agent
+// accumulators live in a per-env HBM scratch (RLay below), the instance fields in the env record that dcm_load_instances
+// filled.  Unlike RL mode a task may collect more members than its requirement, so member slots are sized by `member_cap`
+// (<= 32) and walked with runtime loops.
 //
-// The kernel runs one wave per SIMD at best (LDS capacity), i.e. every instruction costs its full issue latency
-// (~4 clocks) and every dependent LDS access a full round trip (~64): what counts is the number of both per agent
-// step.  Like task_update, agent_update is therefore incremental after an agent_step (only the agents whose inputs
-// the step changed are recomputed), and each phase issues its LDS reads back to back before it uses any of them.
+// With the whole state in LDS the kernel ran one wave per SIMD (every instruction at its full issue latency, every dependent
+// LDS access a full round trip); with 11.7 KB per env at 100A/500T fourteen waves share a CU and the CU's single scalar unit
+// is the busiest resource, so what counts is the number of scalar instructions per agent step.  Like task_update,
+// agent_update is incremental after an agent_step (only the agents whose inputs the step changed are recomputed), each phase
+// issues its LDS reads back to back before it uses any of them, and wave-uniform words are NOT forced into SGPRs.
 #include "common.hpp"
 
 using namespace dcm;
@@ -55,8 +58,8 @@ struct RLay {
 // own update), time_finish f64[T] (the step hands the joined task's value on in registers), travel_dist and
 // max(arrival_time) f64[A] (loaded and stored by the agent's own step, never waited for).  A wave's global accesses are issued
 // and served in order, so the wave sees its own stores (wavefront-scope fences need no cache action).
-// 100A/500T with member_cap 5: 13.7 KB of LDS per env = ELEVEN resident waves per CU (rounds 1-2: two, with 74 KB; round 3 at
-// first three, then four with 39.3 KB -- one wave per SIMD, every instruction and LDS round trip at full latency).
+// The wake-up times f32[T] are there too (read once per event, eight coalesced loads in flight).  100A/500T with member_cap 5: 11.7 KB
+// of LDS per env = FOURTEEN resident waves per CU (rounds 1-2: two, with 74 KB; round 3 at first three, then four with 39.3 KB).
 __host__ __device__ inline size_t replay_scratch_bytes(int A, int T, int MR) {
     return (size_t)8 * T * MR + (size_t)8 * T + (size_t)16 * A + (((size_t)4 * T + 7) & ~(size_t)7);
 }
