@@ -163,3 +163,29 @@ def test_generalised_visibility_schedule(gpu_device, golden_dir, oracle_lib):
         _check(out, b, o.execute_by_route(True), f"all-visible schedule env{b}")
     with pytest.raises(Exception):
         env.set_visibility(20, 0, 10, 100)
+
+
+def test_replay_placements_agree_at_config5_size(gpu_device):
+    """Full-size property (BASELINE config 5 shape, a batch large enough for the HBM placement to be the automatic one): the replay
+    gives bit-identical results whether its scratch block lives in LDS or in HBM, and the same again on a second run."""
+    import torch
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.instances import generate_batch, synthetic_route_arrays
+    B, A, T = 2048, 100, 500
+    inst = generate_batch(B, A, T, base_seed=5, first=0)
+    routes, route_len = synthetic_route_arrays(inst["req"], A, max_task=100)
+    outs = {}
+    for pl in ("lds", "hbm", "auto", "hbm2"):
+        env = BatchedTaskEnv(B, A, T, device=gpu_device)
+        env.load_instances(**inst)
+        env.load_route_arrays(routes, route_len, member_cap=5)
+        env.set_replay_placement(pl.rstrip("2"))
+        o = env.execute_routes(True)
+        outs[pl] = {k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)}
+        env.close()
+    ref = outs["lds"]
+    assert int(ref["steps"].sum()) > 100 * B and not (ref["flags"] & 0x78).any()
+    for pl in ("hbm", "auto", "hbm2"):
+        for k, v in ref.items():
+            assert torch.equal(v.view(torch.uint8) if v.dtype.is_floating_point else v,
+                               outs[pl][k].view(torch.uint8) if v.dtype.is_floating_point else outs[pl][k]), (pl, k)
