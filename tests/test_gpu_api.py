@@ -225,6 +225,21 @@ def test_full_size_properties(gpu_device):
         # a makespan beyond MAX_TIME only through quirk Q7 (the event that crosses 100 is processed completely)
         assert (sm[:, 3] < 100 + 10 + 5 * 2 ** 0.5 + 5).all()
         assert int(s1.min()) > 0
+        # the same episodes cut into launches of 37 decisions (every launch reloads the record and writes it back; at 50A/200T the
+        # persistent kernel keeps the member arrival times in the HBM record itself) and, in between, one lockstep-API observe
+        env.reset(seeds, observe=False)
+        total = torch.zeros_like(s1)
+        for it in range(64):
+            done = (env.status()["flags"] & 1).bool() if it else torch.zeros_like(s1, dtype=torch.bool)
+            if bool(done.all()):
+                break
+            # (an env whose episode is over would start the next one: budget 0 leaves it where it is)
+            total += env.rollout_random(1, max_decisions=torch.where(done, 0, 37).to(torch.int64))
+            if it == 3:
+                env.observe()
+        assert torch.equal(total, s1) and torch.equal(env.summary(), sm1)
+        ts2 = env.tasks_state()
+        assert all(torch.equal(ts2[k], v) for k, v in ts.items())
 
 
 @pytest.mark.parametrize("A,T,policy", [(8, 14, "first"), (20, 50, "random"), (3, 40, "random"), (33, 9, "random"), (70, 70, "last")])
