@@ -341,9 +341,11 @@ def config7(A=20, T=50):
     buffers (runner.py:58-71, worker.py:41-112), decisions recorded per second of job wall time."""
     from dcmrta_amd.runner import BatchedRunner
     rows = {}
-    for B, prec, twin in ((256, "fp32", False), (256, "fp32", True), (4096, "fp32", False), (4096, "fp32", True), (4096, "fp16", False)):
+    for B, prec, twin, tune in ((256, "fp32", False, False), (256, "fp32", True, False), (4096, "fp32", False, False), (4096, "fp32", True, False),
+                                (4096, "fp16", False, False), (4096, "fp32", False, True), (4096, "fp16", False, True)):
         torch.manual_seed(0)
-        r = BatchedRunner(n_envs=B, device=DEV, rollout_precision=prec, twin_rollout=twin)
+        r = BatchedRunner(n_envs=B, device=DEV, rollout_precision=prec, twin_rollout=twin, tune_gemms=tune,
+                          gemm_tuning_file=os.path.join(os.environ.get("TMPDIR", "/tmp"), "dcmrta_runner_tunableop.csv"))
         w = {k: v.clone() for k, v in r.get_weights().items()}
         r.job(w, w, 0, A, T)                                   # captures the graphs
         sync(); t0 = time.perf_counter()
@@ -353,10 +355,12 @@ def config7(A=20, T=50):
         t0 = time.perf_counter()
         lists = [list(x.unbind(0)) if isinstance(x, torch.Tensor) else x for x in res]
         t_lists = time.perf_counter() - t0
-        rows[f"B{B}_{prec}" + ("_twin_batch" if twin else "")] = dict(recorded_decisions=n, job_seconds=wall, recorded_decisions_per_s=n / wall,
+        rows[f"B{B}_{prec}" + ("_twin_batch" if twin else "") + ("_tuned_gemms" if tune else "")] = dict(recorded_decisions=n, job_seconds=wall, recorded_decisions_per_s=n / wall,
                                     sim_decisions_per_s=(n + int(r.last["greedy_rec"]["active"].sum()) if r.last["greedy_rec"] else 2 * n) / wall,
                                     unbind_to_lists_seconds=t_lists, makespan=metrics["makespan"])
         r.close()
+    import torch.cuda.tunable as tunable
+    tunable.enable(False)
     return dict(config=7, workload=f"BatchedRunner.job at {A}A/{T}T (sampled episode + greedy twin + 9-slot experience per env)", **rows,
                 reference_python="~80 recorded decisions/s per Ray worker process (BASELINE.md)")
 

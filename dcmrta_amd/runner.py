@@ -39,7 +39,7 @@ class EnvError(RuntimeError):
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
                  rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets="auto", episode_stride=None,
-                 env_offset=0, strict_mask=False, twin_rollout=False):
+                 env_offset=0, strict_mask=False, twin_rollout=False, tune_gemms=False, gemm_tuning_file=None):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
@@ -47,7 +47,12 @@ class BatchedRunner:
         (1.0, 0.5, 0.25) -- the policy runs only on the envs still active once half / three quarters of the episodes are
         over (GraphedRollout compaction; worthwhile when the forward is much more expensive than the env step).  "auto" (default):
         (1.0, 0.5, 0.25, 0.125) from 1024 envs on -- a 4096-env job of the attention policy takes 1.8 instead of 2.2 s -- none
-        below (the loop is launch-bound there and three more graphs per shape and rollout kind only cost capture time)."""
+        below (the loop is launch-bound there and three more graphs per shape and rollout kind only cost capture time).
+        tune_gemms: before the rollout graphs of a new (net, shape) are captured, the policy is run once at every batch size the
+        graphs will use with PyTorch's TunableOp tuning switched on (stock torch.cuda.tunable: picks the fastest rocBLAS /
+        hipBLASLt solution per GEMM shape; 8.0 -> 6.8 ms per fp32 forward at 4096 x 20A/50T) and the selection is kept for the
+        graphs.  Tuning a shape takes about a minute and a half the first time; the results accumulate in `gemm_tuning_file`
+        (default: PyTorch's own tunableop_results file) across rounds and runs, so it pays for long trainings, not for one job."""
         self.metaAgentID = metaAgentID
         self.device = torch.device(device)
         self.B = int(n_envs)
@@ -63,6 +68,13 @@ class BatchedRunner:
         # policy forward, one graph replay and one tail per decision instead of two -- what pays when the loop is launch-bound
         # (small batches) or the tail of finishing episodes is long
         self.twin_rollout = bool(twin_rollout)
+        self.tune_gemms = bool(tune_gemms)
+        if self.tune_gemms:
+            import torch.cuda.tunable as tunable
+            tunable.enable(True)
+            tunable.tuning_enable(False)
+            if gemm_tuning_file:
+                tunable.set_filename(str(gemm_tuning_file))
         self.episode_stride = int(episode_stride) if episode_stride is not None else self.B
         self.env_offset = int(env_offset)
         if self.episode_stride < self.B:
@@ -193,9 +205,28 @@ class BatchedRunner:
             g = GraphedRollout(env, policy, check_every=self.check_every, record=record, capacity=self.max_steps,
                                buckets=self.buckets)
             slot["graphs"][key] = g
+            if self.tune_gemms and (id(net), "tuned") not in slot:
+                self._tune(net, env, seeds, g.sizes)
+                slot[(id(net), "tuned")] = True
         summary, n = g.run(seeds)
         rec = {k: v[:n] for k, v in g.rec.items()} if record else None
         return summary, rec, n
+
+    @torch.no_grad()
+    def _tune(self, net, env, seeds, sizes):
+        """One forward per batch size with TunableOp tuning on -- never inside a graph capture -- then tuning off again (the
+        selection stays in use)."""
+        import torch.cuda.tunable as tunable
+        from .graph_rollout import CAPTURE_LOCK
+        with CAPTURE_LOCK:
+            obs = env.reset(seeds)
+            tunable.tuning_enable(True)
+            try:
+                for n in sizes:
+                    net(obs.tasks[:n], obs.agents[:n], obs.mask[:n])
+                torch.cuda.synchronize(env.device)
+            finally:
+                tunable.tuning_enable(False)
 
     def _rollout_eager(self, policy, env, seeds, record):
         """The same loop as plain launches with a host sync per decision (debugging / comparison)."""

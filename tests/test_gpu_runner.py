@@ -396,3 +396,28 @@ def test_concurrent_actors_capture_while_others_replay(gpu_device):
     exp = single.testing(seeds=seeds)
     single.close()
     assert np.array_equal(np.array(got), exp)
+
+
+def test_tuned_gemms_job_replays_through_the_oracle(gpu_device, oracle_lib, tmp_path):
+    """BatchedRunner(tune_gemms=True): the policy is run with TunableOp tuning on before the rollout graphs are captured, the graphs
+    then use the selected GEMMs; the recorded episodes are still episodes of the reference env."""
+    import torch.cuda.tunable as tunable
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.runner import BatchedRunner
+    torch.manual_seed(1)
+    B, A, T = 8, 10, 20
+    r = BatchedRunner(n_envs=B, device=gpu_device, net_factory=lambda: AttentionNet(6, 5, 32), base_seed=3, tune_gemms=True,
+                      gemm_tuning_file=str(tmp_path / "tunableop.csv"))
+    try:
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        r.keep_greedy_record = True
+        w = {k: v.clone() for k, v in r.get_weights().items()}
+        r.job(w, w, episodeNumber=0, agents_num=A, tasks_num=T, as_lists=False)
+        assert not tunable.tuning_is_enabled()                       # tuning only around the warm-up forwards
+        inst = generate_batch(B, A, T, base_seed=3, first=0)
+        _replay_recorded(oracle_lib, r.last["greedy_rec"], r.last["greedy_summary"].cpu().numpy(), inst, env_seeds(3, 0, B), A, T)
+    finally:
+        r.close()
+        tunable.enable(False)
