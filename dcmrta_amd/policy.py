@@ -37,7 +37,12 @@ def _pad_rows(x):
 def _layer_norm(x, ln):
     """nn.LayerNorm over the last dim, evaluated as a one-group GroupNorm of the [rows, D] matrix: the same arithmetic
     (per-row moments over D, per-channel affine), but at D = 128 and ~2e5 rows torch's layer-norm kernel takes 213 us per
-    call on MI355X and its group-norm kernels 110 us (tools/policy_bench.py)."""
+    call on MI355X and its group-norm kernels 110 us (tools/policy_bench.py).  Only without autograd (rollouts): the BACKWARD of
+    that group-norm call reduces the affine parameters' gradients over the ~1e5 rows one "sample" at a time
+    (GammaBeta1dBackwardCUDAKernel2: 94 of the 162 ms of a forward + backward over 8192 decisions, tools/policy_bwd_breakdown.py),
+    so a forward that is going to be differentiated uses the layer-norm kernels."""
+    if torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad):
+        return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
     return F.group_norm(x.reshape(-1, x.shape[-1]), 1, ln.weight, ln.bias, ln.eps).view(x.shape)
 
 
