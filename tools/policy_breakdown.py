@@ -28,6 +28,15 @@ with torch.no_grad():
         m(tasks, agents, mask)
     e1.record(); torch.cuda.synchronize()
     print(f"{prec} B={B}: {e0.elapsed_time(e1) / 10:.3f} ms per forward (eager)")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(tasks, agents, mask)
+    g.replay(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{prec} B={B}: {e0.elapsed_time(e1) / 10:.3f} ms per forward (HIP graph)")
     with profile(activities=[ProfilerActivity.CUDA]) as p:
         for _ in range(5):
             m(tasks, agents, mask)
