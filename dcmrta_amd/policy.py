@@ -98,11 +98,12 @@ class GatedFFN(nn.Module):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         n = self.CHUNK_BYTES // (2 * self.hidden * x2.element_size())
-        if x2.shape[0] > 2 * n and not (torch.is_grad_enabled() and (x2.requires_grad or self.W2.weight.requires_grad)):
+        if x2.element_size() >= 4 and x2.shape[0] > 2 * n and not (torch.is_grad_enabled() and (x2.requires_grad or self.W2.weight.requires_grad)):
             # Rollout batch sizes (2e5 token rows): in row chunks, so that the [rows, 1024] product of the first GEMM is still in
             # the 256 MB MALL when F.glu and the second GEMM read it back instead of making two round trips through HBM
-            # (1.15 -> 1.01 ms per call in fp32, 0.45 -> 0.38 in fp16 at 4096 x 51 rows, tools/ffn_chunk_probe.py).  Same
-            # arithmetic per row; hipBLASLt may pick another tile for the smaller M (differences of the last bit).
+            # (1.15 -> 1.01 ms per call in fp32 at 4096 x 51 rows, tools/ffn_chunk_probe.py; +1.5 ... 3 % on every fp32 row of
+            # bench_configs.py --config 3).  fp32 only: with TunableOp-selected GEMMs the 2-byte shadows were 3 % FASTER in one
+            # pass.  Same arithmetic per row; hipBLASLt may pick another tile for the smaller M (differences of the last bit).
             y = torch.empty_like(x2)
             for lo in range(0, x2.shape[0], n):
                 xs = x2[lo:lo + n]
