@@ -39,7 +39,7 @@ class EnvError(RuntimeError):
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
                  rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets="auto", episode_stride=None,
-                 env_offset=0, strict_mask=False, twin_rollout=False, tune_gemms=False, gemm_tuning_file=None):
+                 env_offset=0, strict_mask=False, twin_rollout="auto", tune_gemms=False, gemm_tuning_file=None):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
@@ -67,7 +67,9 @@ class BatchedRunner:
         # of 2 n_envs (rows [0, B) sample, rows [B, 2B) take the argmax of the same net on the same instance and seed): one
         # policy forward, one graph replay and one tail per decision instead of two -- what pays when the loop is launch-bound
         # (small batches) or the tail of finishing episodes is long
-        self.twin_rollout = bool(twin_rollout)
+        # ("auto": below 1024 envs -- 8.5e4 -> 1.4e5 recorded decisions/s at 256 envs; from there on the forward is throughput-bound
+        #  and two batches of B cost the same as one of 2 B)
+        self.twin_rollout = (self.B < 1024) if twin_rollout == "auto" else bool(twin_rollout)
         self.tune_gemms = bool(tune_gemms)
         if self.tune_gemms:
             import torch.cuda.tunable as tunable
@@ -328,7 +330,9 @@ class BatchedRunner:
         info = {"id": self.metaAgentID, "episode_number": episodeNumber}
         if truncated:
             info["truncated_episodes"] = truncated
-        self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps, greedy_steps=g_steps,
+        # (rec: the sampled episodes' [n_steps, B, ...] record -- views of the graph's static buffers, valid until the next recorded
+        #  rollout of this shape)
+        self.last = dict(summary=summary, greedy_summary=greedy_summary, n_steps=n_steps, greedy_steps=g_steps, rec=rec,
                          greedy_rec=grec, truncated=truncated)
         return jobResults, metrics, info
 

@@ -78,7 +78,7 @@ def main():
         res, metrics, info = sr.job(rnd, A, T)
         torch.cuda.synchronize()
         if args.dump:
-            rec = sr.runner._slot(A, T)["graphs"][(id(sr.runner._rollout_net()), "sample", True)].rec
+            rec = sr.runner.last["rec"]                      # the sampled episodes' record [n_steps, B_local, ...]
             n = sr.runner.last["n_steps"]
             np.savez(os.path.join(args.dump, f"round{rnd}_rank{ctx.rank}.npz"), A=A, T=T, lo=sr.lo, hi=sr.hi,
                      returns=info["returns"].cpu().numpy(), summary=sr.runner.last["summary"].cpu().numpy(),
