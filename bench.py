@@ -401,6 +401,8 @@ def main():
     # SURVEY.md §8(d) prices a decision with W = 2S + O + 4 algorithmic bytes whatever the kernel really moves; for the
     # LDS-resident kernels that figure is NOT a utilisation (it exceeds the HBM peak) and is reported only for the record
     roof["w_scored"] = {"algorithmic_bytes_per_step": Wb, "equiv_GBps": dec_per_step * Wb / step_s / 1e9,
+                        # measured HBM traffic as a fraction of the algorithmic bytes of the same steps (<< 1: state resident in LDS)
+                        "traffic_over_algorithmic": (roof["traffic"] / (dec_per_step * Wb)) if roof.get("traffic") else None,
                         "note": "SURVEY §8(d) pricing; the record never leaves LDS, see roofline.hbm for real traffic"}
     what = (f"route replay with dynamic task arrivals (visibility schedule initial,batch,period,cap = {visibility}"
             + (", the reference's constants" if visibility == REFERENCE_VISIBILITY else ", GENERALISED: not the reference's constants")
