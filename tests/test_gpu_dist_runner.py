@@ -75,3 +75,15 @@ def test_rank0_learner_variant(gpu_device, tmp_path):
     for a, b in zip(*logs):
         assert a["weights_checksum"] == b["weights_checksum"]
     assert logs[0][0]["weights_checksum"] != logs[0][1]["weights_checksum"]
+
+
+def test_single_rank_round_at_a_compacting_batch_size(gpu_device):
+    """One rank, a batch large enough for the runner's automatic policy compaction (>= 1024 envs: one graph per bucket size) and a
+    learner that walks the round's decisions in minibatches with accumulated gradients: a plain single-GPU training round."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "train_sharded.py"), "--total-envs", "1100", "--rounds", "2",
+                          "--embedding", "32", "--agents", "8", "10", "--tasks", "12", "16", "--minibatch", "4096"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(l["decisions"] > 1100 * 8 and 0.0 < l["success_rate"] <= 1.0 for l in lines)
+    assert lines[0]["weights_checksum"] != lines[1]["weights_checksum"]        # the optimizer step moved the weights
