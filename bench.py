@@ -20,8 +20,8 @@ the timed region starts.  There is no data-path collective; one RCCL all-gather 
 episode of the pass: returns[B_local, episodes]) -- the analogue of ray.get in driver.py:129-130 -- issued asynchronously so
 that it overlaps with the next pass.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--streams S]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|4|5] [--streams S]      (N > 1: starts its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...  (a launcher's ranks are used as is)
 
 --streams S: the rank's env block is cut into S contiguous sub-batches, each with its own handle and HIP stream.  A pass
 is then S launches; a launch lasts as long as its slowest env, and with several independent streams one sub-batch's tail
@@ -34,6 +34,16 @@ import os
 import sys
 import time
 
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `python bench.py --gpus N` with no launcher around it: this process -- which has not imported torch and never touches
+    # HIP -- starts the N ranks as children (python -m torch.distributed.run ... bench.py <same argv>), relays rank 0's JSON
+    # line and exits with their code.  The reference's driver starts its own 8 actors the same way (driver.py:99).
+    from dcmrta_amd.launch import maybe_self_launch
+    maybe_self_launch(__file__)
+
 # The sub-batches of a pass run on separate HIP streams; the runtime maps streams onto 4 hardware queues by default and
 # kernels that share a queue serialise.  Must be set before the HIP runtime initialises (measured on MI355X, 4096 envs:
 # 4 streams on 4 queues 5.3e8 steps/s, on 8 queues 9.5e8).  (tools/profile.sh exports it too: under rocprofv3 the profiler
@@ -42,9 +52,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
 
 from dcmrta_amd import _lib  # noqa: E402
 from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
@@ -425,7 +432,8 @@ def main():
                    "visibility": ("static" if static_replay else list(visibility)) if replay else None,
                    "sharding": f"env batch x{ctx.world}, no data-path collective"
                                + (f", one async all-gather of the {EP} episode return(s) of every env per pass" if ctx.active else ""),
-                   "dist_backend": ctx.backend or None},
+                   "dist_backend": ctx.backend or None, "world": ctx.world, "process_group_ranks": ctx.group_size(),
+                   "self_launched": os.environ.get("DCM_SELF_LAUNCHED") is not None},
         "roofline": roof,
     }
     if ctx.world == 1 and not args.no_cpu_baseline:

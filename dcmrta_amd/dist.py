@@ -63,8 +63,8 @@ class DistContext:
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if expected_world is not None and expected_world != world:
-            raise RuntimeError(f"--gpus {expected_world} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                               f"--nproc-per-node {expected_world}")
+            raise RuntimeError(f"--gpus {expected_world} but WORLD_SIZE={world}: either start the script plainly (it launches "
+                               f"its own ranks, dcmrta_amd/launch.py) or use torch.distributed.run --nproc-per-node {expected_world}")
         if device is None:
             # DCM_FORCE_DEVICE lets several ranks share one GPU (functional smoke of the N>1 path on a 1-GPU box,
             # together with DCM_DIST_BACKEND=gloo; RCCL itself needs one device per rank)
@@ -184,6 +184,10 @@ class DistContext:
         t = torch.tensor([x], dtype=torch.int64, device=self._coll_device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
+
+    def group_size(self):
+        """Rank count as the process group (RCCL / gloo) itself reports it; None without a group."""
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else None
 
     def shutdown(self):
         if self._active():

@@ -118,3 +118,34 @@ def test_config5_replay_line(gpu_device):
     assert "GENERALISED" in j["config"]["workload"] and j["config"]["visibility"] == [100, 100, 10, 500]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "execute_by_route" in c["sample"]
+
+
+@pytest.mark.parametrize("extra,check", [
+    (["--envs", "512"], lambda j: j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 512 and j["config"]["envs_total"] == 1024),
+    (["--config", "4", "--envs", "600"], lambda j: j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 300 and j["config"]["tasks"] == 200),
+    (["--config", "5", "--envs", "200"], lambda j: j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 100 and j["roofline"]["kernel"] == "k_replay"),
+], ids=["config2", "config4", "config5"])
+def test_plain_command_launches_its_own_ranks(gpu_device, extra, check):
+    """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1, with NO torch.distributed.run around it: the
+    parent starts the two ranks itself before touching the GPU (dcmrta_amd/launch.py), rank 0's single line comes back through
+    it.  Two ranks share the test box's one GPU over gloo; on a multi-GPU node the same command runs one rank per GPU over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DCM_FORCE_DEVICE="0", DCM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
+    assert j["config"]["world"] == 2 and j["config"]["process_group_ranks"] == 2 and j["config"]["dist_backend"] == "gloo"
+    assert j["config"]["self_launched"] is True and check(j)
+    assert "cpu_baseline" not in j
+
+
+def test_plain_command_propagates_rank_failure(gpu_device):
+    """A rank that dies takes the job down with a non-zero exit code and no JSON line (here: an impossible shape)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DCM_FORCE_DEVICE="0", DCM_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--agents", "4000"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
