@@ -1418,6 +1418,8 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
     S.store_record(rec, lane);
 }
 
+#include "rollout_fast.hpp"
+
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
     const int e = blockIdx.x * WAVE + threadIdx.x;
@@ -1547,6 +1549,8 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
 // the reference's training range A <= 20, T <= 50 (parameters.py:15-16); <64,64,runtime sizes> for the remaining one-chunk
 // shapes (A <= 64, T <= 64: one lane per agent / task); <0,0> for the rest.
 #define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(64, 64, true); X(50, 200, false); X(100, 500, false); X(0, 0, false)
+// one-chunk layouts: the register-resident persistent kernel (rollout_fast.hpp)
+#define FOR_EACH_FAST(X) X(20, 50, false); X(20, 50, true); X(64, 64, true)
 #define DISPATCH_ENV(env, CALL)                                                                        \
     do {                                                                                               \
         const dcm_env* e_ = (env);                                                                     \
@@ -1633,6 +1637,11 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     FOR_EACH_INSTANCE(SET_ATTR);
 #undef SET_ATTR
+#define SET_FAST(CA, CT, RS)                                                                                              \
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    FOR_EACH_FAST(SET_FAST);
+#undef SET_FAST
     (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_get_agents, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = h;
@@ -1763,6 +1772,26 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
+#ifndef DCM_NO_FAST_ROLLOUT
+    // One-chunk layouts (one lane per agent and per task, lane 63 free for the depot) with all three observation buffers or
+    // none: the register-resident kernel.  Same contract, same results (tests/test_gpu_rollout.py runs both).
+    const bool all_obs = agents_out && tasks_out && mask_out, no_obs = !agents_out && !tasks_out && !mask_out;
+    if (env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
+#define CALLF(CA, CT, RS, OBS)                                                                                        \
+    hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS>), GRID(env),                                                  \
+                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
+                       env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
+#define CALL(CA, CT, RS) do { if (all_obs) { CALLF(CA, CT, RS, true); } else { CALLF(CA, CT, RS, false); } } while (0)
+        const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
+        if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
+        else { CALL(64, 64, true); }
+#undef CALL
+#undef CALLF
+        LAUNCH_OK();
+        return DCM_OK;
+    }
+#endif
 #define CALL(CA, CT, RS)                                                                                              \
     hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS, ((CT) > WAVE) && !(RS)>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \

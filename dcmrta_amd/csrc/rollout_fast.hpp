@@ -1,0 +1,445 @@
+// rollout_fast.hpp -- the persistent rollout kernel of the ONE-CHUNK layouts (A <= 64, T <= 63: one lane per agent and per task):
+// lane-owned state lives in REGISTERS for the whole fast path, LDS is only the cross-lane exchange.
+// Included by dcmrta_env.hip inside its anonymous namespace, after Sim<>.
+//
+// Why: k_rollout_random keeps the record in LDS and re-reads every field in every phase of a decision -- ~60 LDS instructions in
+// ~12 DEPENDENT round trips, each phase fenced from the next, and (round-3 profile) 0.39 of the wave time parked on s_waitcnt,
+// 347 scalar + 89 branch instructions per decision, most of them the compiler's exec-mask bookkeeping around guarded lane loops
+// and error returns.  With four waves per SIMD (4096 envs on 1024 SIMDs) the kernel is bound by ONE wave's critical path, so the
+// cure is fewer dependent steps, not more parallelism:
+//   * lane a owns agent a (x, y, arrival, next_decision, travel_dist, route[-1], flags), lane t owns task t (status word,
+//     time_start, time_finish, ordered member ids, and the read-only x, y, duration); lane 63 owns the depot as a pseudo-task
+//     (its observation row 0 and mask byte 0 leave in the same store instructions as the task rows);
+//   * wave-uniform reads of a chosen lane's state (the leader's position, the chosen task's status word / ids / position) are
+//     v_readlane -- no LDS round trip; per-lane reads of own state cost nothing;
+//   * LDS carries only what another lane must read by INDEX: the member arrival slots f64[M][T] (written by the joining agents'
+//     lanes, read by the task's lane), the status words and the two time arrays (written through by the task lanes, gathered by
+//     the agents' lanes in agent_update), and -- for the member-removal path, which scatters from a task's lane to its members --
+//     route[-1] and the flag words of the agents (written through by agent_step);
+//   * the lane code is select-based (no per-lane branches except the member-removal compaction), error returns do not exist on
+//     this path (the device policy only takes valid actions on a validated instance), the observation pointers are a template
+//     parameter, and every loop / branch condition is wave-uniform in SGPRs.
+// Everything that happens once per episode or less -- reset, the terminal metrics, events at which nobody can decide, the first
+// event of an episode -- runs the verified Sim<> code on the LDS image: the fast path flushes its registers, calls it, reloads.
+//
+// Reference restated: worker.py:45-87 (loop), env/task_env.py:161-342 (the functions named at each block below).
+#pragma once
+
+template <int CA, int CT, bool RS, bool OBS>
+struct Fast {
+    using SimT = Sim<CA, CT, RS, false>;
+    using AMask = typename SimT::AMask;
+    static_assert(CA >= 1 && CA <= 64 && CT >= 1 && CT <= 64, "one lane per agent / task; lane 63 is the depot's (the host dispatches T <= 63 only)");
+    static constexpr int DL = 63;                     // depot lane
+    static constexpr Lay L{CA, CT};
+
+    SimT S;
+    uint64_t am, tm;                                   // lanes that own an agent / a task (wave-uniform masks)
+    // per-lane constants
+    bool inA, inT, isD;
+    int la, lt;                                        // clamped own agent / task index (0 for the lanes that own none)
+
+    struct R {
+        double ax, ay, arr, nd, td;                    // agent: location, arrival_time[-1], next_decision, travel_dist
+        int32_t cur; uint32_t ai;                      //        route[-1], ainfo word
+        double cts, cdur;                              //        time_start / duration of route[-1] as of the last agent_update
+        uint32_t ti; double ts, tf; uint64_t ids;      // task:  tinfo word, time_start, time_finish, ordered member ids
+        double tx, ty, dur;                            //        instance (depot lane: depot x, y, 0)
+    };
+
+    __device__ __forceinline__ void init(int lane) {
+        const int A_ = S.A(), T_ = S.T();
+        am = A_ >= 64 ? ~0ull : ((1ull << A_) - 1ull);
+        tm = (1ull << T_) - 1ull;
+        inA = lane < A_; inT = lane < T_; isD = lane == DL;
+        la = inA ? lane : 0; lt = inT ? lane : 0;
+    }
+    // position of the idx-th (0-based) set bit of m, idx < popcount(m): the lanes up to and including it are exactly those with
+    // fewer than idx + 1 set bits below them
+    __device__ __forceinline__ static int nth(uint64_t m, int idx) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        return __popcll(__ballot(rank <= idx)) - 1;
+    }
+    __device__ __forceinline__ static double rl(double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    }
+    __device__ __forceinline__ static uint64_t rl(uint64_t v, int src) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    }
+
+    // ------------------------------------------------------------------------------ registers <-> LDS image
+    __device__ __forceinline__ void load_consts(R& r) const {
+        r.tx = isD ? ((const Hdr*)S.base)->depot_x : S.tx()[lt];
+        r.ty = isD ? ((const Hdr*)S.base)->depot_y : S.ty()[lt];
+        r.dur = isD ? 0.0 : S.tdur()[lt];
+    }
+    __device__ __forceinline__ void reload(R& r) const {
+        r.ax = S.ax()[la]; r.ay = S.ay()[la]; r.arr = S.arr()[la]; r.nd = S.nd()[la]; r.td = S.tdist()[la];
+        r.cur = S.cur()[la]; r.ai = S.ainfo()[la];
+        const int K = r.cur < 0 ? 0 : r.cur;
+        r.cts = S.ts()[K]; r.cdur = S.tdur()[K];
+        r.ti = S.tinfo()[lt]; r.ts = S.ts()[lt]; r.tf = S.tf()[lt]; r.ids = S.mids()[lt];
+    }
+    // what the fast path keeps in registers only (everything else is written through when it changes)
+    __device__ __forceinline__ void flush(const R& r) const {
+        if (inA) {
+            S.ax()[la] = r.ax; S.ay()[la] = r.ay; S.arr()[la] = r.arr; S.nd()[la] = r.nd; S.tdist()[la] = r.td;
+            S.ainfo()[la] = r.ai;
+        }
+        if (inT) S.mids()[lt] = r.ids;
+        WSYNC();
+    }
+
+    // ------------------------------------------------------------------------------ task_update, env/task_env.py:245-281
+    // One lane per task, inputs from the lane's registers + the member arrival slots in LDS.  Returns with tinfo / time_start /
+    // time_finish written through for agent_update's gather.
+    __device__ __forceinline__ void task_update(R& r, double now, double mwt, int lane) const {
+        uint32_t info = r.ti;
+        const bool feas0 = info & T_FEAS;
+        const int req = info & 0xFF, n = (info >> 16) & 0xFF;                    // :250
+        double av[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) av[j] = S.marr()[j * CT + lt];               // :251 (unused slots hold NaN)
+        const double tfin = r.tf, dur = r.dur;
+        const int status = req - n;                                              // :252
+        double mx = av[0], mn = av[0];
+#pragma unroll
+        for (int j = 1; j < M; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
+        const bool le0 = status <= 0;                                            // :254
+        const bool ok = le0 && (mx - mn <= mwt);                                 // :255
+        const double thr = mx - mwt;                                             // :262
+        // does any member leave?  (see Sim::task_update: decided on the earliest arrival alone)
+        const bool any_drop = inT && !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
+        const bool becomes = !feas0 && ok;                                       // :256-258
+        const double nts = becomes ? mx : r.ts, ntf = becomes ? mx + dur : tfin;
+        int nn = n;
+        if (any_drop) {   // the one divergent branch: compact the surviving members in order (Q1 for the waiting branch)
+            uint32_t spread = 0, q1 = 0;
+            bool prev = false;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                spread |= (av[j] <= thr) ? (1u << j) : 0u;                       // :262-265
+                const bool e = !prev && (now - av[j] >= mwt);                    // :268-271 remove-while-iterating
+                q1 |= e ? (1u << j) : 0u;
+                prev = e;
+            }
+            const uint32_t drop = le0 ? spread : q1;
+            const uint64_t ids = r.ids;
+            uint64_t nids = 0;
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < M; j++) if (j < n) {
+                const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
+                if (drop & (1u << j)) {
+                    const uint32_t nth_ = atomicAdd(&S.ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
+                    if (nth_ < (uint32_t)AB_CAP) S.ablog()[id * AB_CAP + nth_] = (uint16_t)lt;
+                    else { const uint32_t ci = (uint32_t)(id * S.T() + lt); atomicAdd((uint32_t*)S.abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
+                    if (S.cur()[id] == lt) atomicAnd(&S.ainfo()[id], ~A_MEMBER);
+                } else {
+                    nids |= (uint64_t)id << (8 * k);
+                    S.marr()[k * CT + lt] = av[j];
+                    k++;
+                }
+            }
+            for (int j = k; j < n; j++) S.marr()[j * CT + lt] = __builtin_nan("");
+            r.ids = nids;
+            S.tnab()[lt] += (uint32_t)(n - k);
+            nn = k;
+        }
+        const uint32_t info_i = ((info | (ok ? T_FEAS : 0u)) & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
+        const uint32_t info_f = info | ((now >= tfin) ? T_FIN : 0u);             // :273-274
+        info = feas0 ? info_f : info_i;
+        r.ti = info; r.ts = nts; r.tf = ntf;
+        if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
+        const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
+        const bool dropped = __ballot(any_drop) != 0ull;
+        WSYNC();
+        if (dropped) {
+            // the removal path counted the abandonment in the agent's LDS flag word and cleared its membership bit there: take both
+            const uint32_t w = S.ainfo()[la];
+            r.ai = (r.ai & 0xFFFFu & (w | ~A_MEMBER)) | (w & 0xFFFF0000u);
+        }
+        if (all_feasible) {                                                      // depot :277-280
+            if ((r.ai & A_INDEPOT) && now >= r.arr) r.ai |= A_RETURNED;
+        }
+    }
+
+    // ------------------------------------------------------------------------------ agent_update, env/task_env.py:207-243
+    __device__ __forceinline__ void agent_update(R& r, double now, double mwt) const {
+        const int c = r.cur;
+        const int K = c < 0 ? 0 : c;
+        const uint32_t gi = S.tinfo()[K];                                        // :228
+        const double gts = S.ts()[K], gtf = S.tf()[K], gdur = S.tdur()[K];
+        const bool member = (gi & T_FEAS) && (r.ai & A_MEMBER);                  // :229-230
+        const double ndv = (c == -1) ? __builtin_nan("") : (member ? gtf : r.arr + mwt);   // :226,:231,:235,:238
+        const uint32_t as = member ? ((r.ai & A_ASSIGNED) | ((now >= gts) ? A_ASSIGNED : 0u)) : 0u;   // :232-240
+        r.nd = (c != -2) ? ndv : r.nd;                                           // :209
+        r.ai = (c >= 0) ? ((r.ai & ~A_ASSIGNED) | as) : r.ai;                    // depot leaves `assigned` untouched (Q6)
+        r.cts = gts; r.cdur = gdur;
+    }
+
+    // ------------------------------------------------------------------------------ observation, worker.py:57-68
+    // env/task_env.py:165-200 relative to the leader; rows straight into the policy's input tensors.  Returns the ballot of the
+    // unmasked tasks (the random policy picks from it).
+    __device__ __forceinline__ uint64_t observe(const R& r, double now, int leader, float* __restrict__ agrow, float* __restrict__ tkrow,
+                                                uint8_t* __restrict__ mkp) const {
+        const double lx = rl(r.ax, leader), ly = rl(r.ay, leader);
+        if constexpr (OBS) {
+            const bool on = r.cur >= 0;                                          // :168
+            const double x = r.arr - now, w = now - r.arr, rem = r.cts + r.cdur - now;
+            const double travel = (on && x > 0.) ? x : 0.;                       // :169
+            const double waiting = (on && now <= r.cts && w > 0.) ? w : 0.;      // :170
+            const double remaining = (on && now >= r.cts && rem > 0.) ? rem : 0.;   // :171
+            const float f0 = (float)travel, f1 = (float)remaining, f2 = (float)waiting;
+            const float f3 = (float)(lx - r.ax), f4 = (float)(ly - r.ay), f5 = (r.ai & A_ASSIGNED) ? 1.f : 0.f;
+            if (inA) { agrow[0] = f0; agrow[1] = f1; agrow[2] = f2; agrow[3] = f3; agrow[4] = f4; agrow[5] = f5; }   // :176-177
+        }
+        const uint32_t info = isD ? 0u : r.ti;
+        const int status = (int)(int8_t)((info >> 8) & 0xFF);
+        const bool unfinished = !(info & T_FEAS) && status > 0;                  // :199
+        const uint64_t bm = __ballot(unfinished) & tm;
+        if constexpr (OBS) {
+            const uint32_t depot_bit = bm ? 1u : 0u;                             // worker.py:58-61
+            const uint8_t mv = isD ? (uint8_t)depot_bit : (uint8_t)(unfinished ? 0 : 1);   // :193
+            const float g0 = (float)status, g1 = (float)(info & 0xFF), g2 = (float)r.dur;
+            const float g3 = (float)(r.tx - lx), g4 = (float)(r.ty - ly);        // :185-188
+            if (inT || isD) { *mkp = mv; tkrow[0] = g0; tkrow[1] = g1; tkrow[2] = g2; tkrow[3] = g3; tkrow[4] = g4; }
+        }
+        return bm;
+    }
+
+    // ------------------------------------------------------------------------------ one decision
+    // worker.py:54-76: leader, observation, uniform-random valid action, TaskEnv.step + agent_step (env/task_env.py:300-342),
+    // task_update, agent_update.  Returns the number of agents of the group that have not acted yet.
+    __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp) const {
+        const double now = h.now;
+        // leader (protocol slot 0)
+        const uint64_t gm = __ballot((int)((r.ai >> 8) & 0xFFu) == h.cur_group) & am;
+        const int glen = __popcll(gm);
+        if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return 0; }    // unreachable: groups are never empty
+        const int leader = nth(gm, below((uint32_t)(k1 >> 32), glen));
+        const uint64_t bm = observe(r, now, leader, agrow, tkrow, mkp);
+        // uniform-random valid action (protocol slot 1)
+        const int nv = __popcll(bm);
+        const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
+        // TaskEnv.step :326-342
+        uint64_t rest = gm & ~(1ull << leader);                                  // :328
+        int rlen = glen - 1;
+        uint64_t mm = 1ull << leader, mlist = (uint64_t)(uint32_t)leader;
+        int nm = 1;
+        const int tl = action ? action - 1 : DL;                                 // lane that owns the target
+        if (action == 0) {                                                       // vacancy = len(group) :327 (Q9)
+            mm |= rest; nm += rlen; rlen = 0;
+        } else if (rlen != 0) {
+            const int vacancy = (int)(int8_t)(((uint32_t)__builtin_amdgcn_readlane((int)r.ti, tl) >> 8) & 0xFF);   // :327 (may be stale)
+            const int nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;   // :330-331
+            uint64_t kk = k1;
+            for (int j = 0; j < nf; j++) {                                       // :331 choice without replacement
+                if ((j & 1) == 0) kk = mix64(kk + GAMMA);
+                const uint32_t rr = (j & 1) ? (uint32_t)kk : (uint32_t)(kk >> 32);
+                const int f = nth(rest, below(rr, rlen));
+                rest &= ~(1ull << f); rlen--;                                    // :332-333
+                mm |= 1ull << f;
+                mlist |= (uint64_t)(uint32_t)f << (8 * nm);
+                nm++;
+            }
+        }
+        const double tx_ = rl(r.tx, tl), ty_ = rl(r.ty, tl);
+        // agent_step :300-324 on all lanes (fp64 work with few active lanes is 4x slower), state changes on the members' lanes
+        const double d = dist2(r.ax, r.ay, tx_, ty_);
+        const double arrv = now + over_velocity(d);                              // :315,:318
+        const bool mem = (mm >> lane) & 1ull;
+        uint64_t ids = 0; uint32_t kinfo = 0; int n = 0;
+        int mypos = 0;
+        bool relisted = false;
+        if (action) {
+            // :321-322 members.append unless already listed (Q4: a re-joining agent keeps its slot, its arrival is overwritten)
+            kinfo = (uint32_t)__builtin_amdgcn_readlane((int)r.ti, tl);
+            ids = rl(r.ids, tl);
+            n = (kinfo >> 16) & 0xFF;
+            // position of this lane in the step's ordered member list; is it already listed in the task?
+            const uint64_t pat = 0x0101010101010101ull * (uint64_t)(uint32_t)lane;
+            const uint64_t xm = mlist ^ pat;
+            uint64_t zm = (xm - 0x0101010101010101ull) & ~xm & 0x8080808080808080ull;
+            zm &= (1ull << (8 * nm)) - 1ull;                                     // nm <= 5
+            mypos = (__ffsll((unsigned long long)zm) - 1) >> 3;
+            const uint64_t xi = ids ^ pat;
+            uint64_t zi = (xi - 0x0101010101010101ull) & ~xi & 0x8080808080808080ull;
+            zi &= (1ull << (8 * n)) - 1ull;                                      // n <= 5
+            relisted = __ballot(mem && zi != 0ull) != 0ull;
+        }
+        int slot = n + mypos;
+        if (relisted) {
+            // rare (Q4): walk the members in order as the reference does; every lane learns its own slot
+            uint64_t ids2 = ids;
+            int n2 = n;
+            for (int j = 0; j < nm; j++) {
+                const int m = (int)((mlist >> (8 * j)) & 0xFF);
+                const uint64_t x = ids2 ^ (0x0101010101010101ull * (uint64_t)(uint32_t)m);
+                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                z &= (n2 >= 8) ? ~0ull : ((1ull << (8 * n2)) - 1ull);
+                int pos;
+                if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                else { pos = n2++; ids2 |= (uint64_t)(uint32_t)m << (8 * pos); }
+                if (lane == m) slot = pos;
+            }
+            ids = ids2; n = n2;
+        } else if (action) {
+            ids |= mlist << (8 * n);                                             // bytes above n are always zero
+            n += nm;
+        }
+        if (mem) {
+            r.td += d;                                                           // :317
+            r.arr = arrv;
+            r.ax = tx_; r.ay = ty_;                                              // :320
+            r.cur = action - 1;                                                  // :314
+            r.ai = (r.ai & ~(A_GRP | A_MEMBER)) | (action == 0 ? A_INDEPOT : A_MEMBER);
+            S.cur()[la] = action - 1; S.ainfo()[la] = r.ai;                      // the member-removal path reads them by index
+            if (action) S.marr()[slot * CT + tl] = arrv;
+        }
+        if (action && lane == tl) { r.ids = ids; r.ti = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
+        WSYNC();
+        task_update(r, now, P.mwt, lane);                                        // worker.py:74
+        agent_update(r, now, P.mwt);                                             // worker.py:76
+        return rlen;
+    }
+
+    // ------------------------------------------------------------------------------ next event (common case)
+    // Boxes D + A of the loop when somebody can decide and MAX_TIME has not passed: next_decision (env/task_env.py:283-289),
+    // get_unique_group (:291-298), task_update, agent_update (worker.py:49-51).  Returns false -- with nothing changed -- when the
+    // event needs the general code (nobody can decide: check_finished :366-373; or the loop test of worker.py:45 ends the episode).
+    __device__ __forceinline__ bool next_event(R& r, HdrRegs& h, const KP& P, int lane) const {
+        if (h.now >= P.max_time) return false;
+        const double ndv = inA ? r.nd : __builtin_nan("");
+        const double tmin = wave_nanmin(ndv);                                    // :287
+        if (!(tmin == tmin)) return false;
+        h.now = tmin;                                                            // worker.py:49
+        const bool dec = (ndv == tmin);                                          // :288 exact ==
+        const uint64_t dm = __ballot(dec);
+        const int first = __ffsll((unsigned long long)dm) - 1;
+        bool same = true;
+        if (dm & (dm - 1ull)) {                                                  // more than one decider: all on one point?
+            const double x0 = rl(r.ax, first), y0 = rl(r.ay, first);
+            same = __ballot(dec && !(r.ax == x0 && r.ay == y0)) == 0ull;
+        }
+        if (same) {
+            r.ai = (r.ai & ~A_GRP) | (dec ? (1u << 8) : 0u);
+            h.n_groups = 1;
+        } else {
+            // groups in ascending (x, then y) order == rows of np.unique(axis=0) :293
+            bool todo = dec;
+            uint32_t gid = 0;
+            int g = 0;
+            for (;;) {
+                const double mxv = wave_nanmin(todo ? r.ax : __builtin_nan(""));
+                if (!(mxv == mxv)) break;
+                const double myv = wave_nanmin((todo && r.ax == mxv) ? r.ay : __builtin_nan(""));
+                g++;
+                if (todo && r.ax == mxv && r.ay == myv) { gid = (uint32_t)g; todo = false; }
+            }
+            r.ai = (r.ai & ~A_GRP) | (gid << 8);
+            h.n_groups = g;
+        }
+        task_update(r, tmin, P.mwt, lane);                                       // worker.py:50
+        agent_update(r, tmin, P.mwt);                                            // worker.py:51
+        h.empty_passes = 0;
+        h.cur_group = 1;
+        return true;
+    }
+};
+
+// Same contract as k_rollout_random (see there); OBS: all three observation buffers given / none of them.
+template <int CA, int CT, bool RS, bool OBS>
+__global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
+                                                      float* agents_out, float* tasks_out, uint8_t* mask_out,
+                                                      int64_t* steps_out, double* summary, uint16_t* ablog,
+                                                      const int32_t* sizes, int64_t budget_all, const int64_t* budget_in,
+                                                      unsigned char* gscr, double* retlog, int retcap) {
+    const int e = env_of_workgroup(), lane = threadIdx.x;
+    int eA, eT;
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    using F = Fast<CA, CT, RS, OBS>;
+    using SimT = typename F::SimT;
+    SimT S{eA, eT, PA, PT, smem, nullptr};
+    const Lay L = S.L();
+    S.scr = SimT::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
+    const int BA = S.BA(A), BT = S.BT(T);
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    typename SimT::XY xy;
+    S.template load_record<true, false>(rec, lane, xy);
+    S.set_ablog(ablog, e, BA, BT, lane);
+    S.set_retlog(retlog, retcap, e, lane);
+    WSYNC();
+    HdrRegs h = load_hdr(smem);
+    F f{S};
+    f.init(lane);
+    float* agrow = nullptr; float* tkrow = nullptr; uint8_t* mkp = nullptr;
+    if constexpr (OBS) {
+        float* ag = agents_out + (size_t)e * 6 * BA;
+        float* tk = tasks_out + (size_t)e * 5 * (BT + 1);
+        uint8_t* mk = mask_out + (size_t)e * (BT + 1);
+        if constexpr (RS) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
+        agrow = ag + 6 * f.la;
+        tkrow = tk + (f.inT ? 5 * (lane + 1) : 0);
+        mkp = mk + (f.inT ? lane + 1 : 0);
+    }
+    double* row = summary + (size_t)e * 8;
+    constexpr int NO_BUDGET = 0x7FFFFFFF;
+    int64_t bud = budget_in ? budget_in[e] : budget_all;
+    const int left0 = uni((int)((bud < 0 || bud >= NO_BUDGET) ? NO_BUDGET : bud));
+    int left = left0;
+    uint64_t gd = h.seed + GAMMA * (h.d + 1);
+    const uint64_t d0 = h.d;
+    typename F::R r;
+    f.load_consts(r);
+    constexpr uint32_t ERR = DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE;
+    PH_DECL;
+    int ep = 0;
+    bool need_adv = false;       // the general event code has to run on the (flushed) LDS image before the next decision
+    for (;;) {
+        if (!need_adv) {         // head of an episode slot (the `for ep` of k_rollout_random)
+            if (ep >= episodes) break;
+            if (h.flags & DCM_FLAG_DONE) {   // restart from the loaded instance; d keeps running
+                if (h.flags & ERR) break;
+                if (left == 0) break;        // budget spent at an episode boundary: the finished episode's results stay readable
+                S.reset_state(h, lane);
+                need_adv = true;
+            }
+        }
+        if (need_adv) { S.advance(h, P, lane, row PH_PASS); need_adv = false; }
+        if (!(h.flags & DCM_FLAG_DONE) && left != 0) {
+            WSYNC();
+            f.reload(r);
+            for (;;) {
+                const uint64_t k1 = mix64(gd);
+                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp);
+                if (h.flags & DCM_FLAG_DONE) break;
+                gd += GAMMA;
+                left--;
+                if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
+                    if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group
+                    else if (!f.next_event(r, h, P, lane)) { need_adv = true; break; }   // worker.py:85 -> :45
+                }
+                if (left == 0) break;
+            }
+            f.flush(r);
+            if (need_adv) continue;
+        }
+        if (left == 0) break;
+        ep++;
+    }
+    PH_FLUSH(lane);
+    const int64_t steps = (int64_t)(left0 - left);
+    if (lane == 0 && steps_out) steps_out[e] = steps;
+    h.d = d0 + (uint64_t)steps;
+    {   // Hdr::max_arrival (see k_rollout_random)
+        double m = 0.0;
+        S.for_agents(lane, [&](int a) { const double av = (S.cur()[a] != -2) ? S.arr()[a] : 0.0; m = av > m ? av : m; });
+        const double wm = wave_nanmax(m);
+        if (lane == 0) { Hdr* q = (Hdr*)smem; if (wm > q->max_arrival) q->max_arrival = wm; }
+    }
+    WSYNC();
+    store_hdr(h, lane);
+    WSYNC();
+    S.store_record(rec, lane);
+}
