@@ -193,6 +193,19 @@ __device__ __forceinline__ double wave_nanmin(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+// The same when only lanes 0..NL-1 can hold a value (the others hold NaN): one or two reduction stages fewer
+template <int NL>
+__device__ __forceinline__ double wave_nanmin_n(double v) {
+    if constexpr (NL > 32) return wave_nanmin(v);
+    v = nanmin2(v, dpp_f64<0x111, 0xF>(v));
+    v = nanmin2(v, dpp_f64<0x112, 0xF>(v));
+    v = nanmin2(v, dpp_f64<0x114, 0xF>(v));
+    v = nanmin2(v, dpp_f64<0x118, 0xF>(v));                    // lane 15 / 31: minimum of row 0 / 1
+    if constexpr (NL > 16) v = nanmin2(v, dpp_f64<0x142, 0xA>(v));   // row_bcast:15 -> lane 31: minimum of rows 0 and 1
+    constexpr int SRC = NL > 16 ? 31 : 15;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_nanmax(double v) {
     v = nanmax2(v, dpp_f64<0x111, 0xF>(v));
     v = nanmax2(v, dpp_f64<0x112, 0xF>(v));

@@ -574,9 +574,6 @@ struct Sim {
     __device__ __noinline__ static bool terminal_metrics(Sim S, double now, double mwt, int lane, double* __restrict__ row) {
         return S.terminal_metrics_body(now, mwt, lane, row);
     }
-    __device__ __noinline__ bool terminal_metrics_m(double now, double mwt, int lane, double* __restrict__ row) const {
-        return terminal_metrics_body(now, mwt, lane, row);
-    }
     __device__ __forceinline__ bool terminal_metrics_body(double now, double mwt, int lane, double* __restrict__ row) const {
         WSYNC();
         const bool over = compute_waits(now, mwt, lane);
@@ -643,11 +640,9 @@ struct Sim {
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt = __builtin_readcyclecounter();
 #endif
-        #ifdef DCM_TERMINAL_MEMBER
-        const bool over = terminal_metrics_m(h.now, P.mwt, lane, row);
-#else
-        const bool over = terminal_metrics(*this, h.now, P.mwt, lane, row);
-#endif
+        // (the out-of-line call returns in a VGPR: without the readfirstlane the compiler treats h.flags -- and with it every loop
+        //  the flags control -- as divergent, and turns the kernels' scalar branches into exec-mask bookkeeping)
+        const bool over = uni((uint32_t)terminal_metrics(*this, h.now, P.mwt, lane, row)) != 0u;
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[15], __builtin_readcyclecounter() - pt);
 #endif

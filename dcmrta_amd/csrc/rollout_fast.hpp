@@ -44,7 +44,9 @@ struct Fast {
         int32_t cur; uint32_t ai;                      //        route[-1], ainfo word
         double cts, cdur;                              //        time_start / duration of route[-1] as of the last agent_update
         uint32_t ti; double ts, tf; uint64_t ids;      // task:  tinfo word, time_start, time_finish, ordered member ids
+        uint64_t lm; uint32_t nab;                     //        the listed members as an agent bitmask; len(abandoned_agent)
         double tx, ty, dur;                            //        instance (depot lane: depot x, y, 0)
+        uint16_t* ab;                                  // agent: its row of the abandonment log (HBM side table)
     };
 
     __device__ __forceinline__ void init(int lane) {
@@ -72,21 +74,26 @@ struct Fast {
         r.tx = isD ? ((const Hdr*)S.base)->depot_x : S.tx()[lt];
         r.ty = isD ? ((const Hdr*)S.base)->depot_y : S.ty()[lt];
         r.dur = isD ? 0.0 : S.tdur()[lt];
+        r.ab = S.ablog() + la * AB_CAP;
     }
     __device__ __forceinline__ void reload(R& r) const {
         r.ax = S.ax()[la]; r.ay = S.ay()[la]; r.arr = S.arr()[la]; r.nd = S.nd()[la]; r.td = S.tdist()[la];
         r.cur = S.cur()[la]; r.ai = S.ainfo()[la];
         const int K = r.cur < 0 ? 0 : r.cur;
         r.cts = S.ts()[K]; r.cdur = S.tdur()[K];
-        r.ti = S.tinfo()[lt]; r.ts = S.ts()[lt]; r.tf = S.tf()[lt]; r.ids = S.mids()[lt];
+        r.ti = S.tinfo()[lt]; r.ts = S.ts()[lt]; r.tf = S.tf()[lt]; r.ids = S.mids()[lt]; r.nab = S.tnab()[lt];
+        r.lm = 0ull;
+        const int n = (r.ti >> 16) & 0xFF;
+#pragma unroll
+        for (int j = 0; j < M; j++) r.lm |= (j < n) ? (1ull << ((r.ids >> (8 * j)) & 0xFF)) : 0ull;
     }
     // what the fast path keeps in registers only (everything else is written through when it changes)
     __device__ __forceinline__ void flush(const R& r) const {
         if (inA) {
             S.ax()[la] = r.ax; S.ay()[la] = r.ay; S.arr()[la] = r.arr; S.nd()[la] = r.nd; S.tdist()[la] = r.td;
-            S.ainfo()[la] = r.ai;
+            S.cur()[la] = r.cur; S.ainfo()[la] = r.ai;
         }
-        if (inT) S.mids()[lt] = r.ids;
+        if (inT) { S.mids()[lt] = r.ids; S.tnab()[lt] = r.nab; }
         WSYNC();
     }
 
@@ -113,38 +120,52 @@ struct Fast {
         const bool becomes = !feas0 && ok;                                       // :256-258
         const double nts = becomes ? mx : r.ts, ntf = becomes ? mx + dur : tfin;
         int nn = n;
-        if (any_drop) {   // the one divergent branch: compact the surviving members in order (Q1 for the waiting branch)
-            uint32_t spread = 0, q1 = 0;
-            bool prev = false;
+        const uint64_t dmask = __ballot(any_drop);
+        if (dmask) {
+            // Members leave (:262-265 spread branch, :268-271 waiting branch with its remove-while-iterating skip, Q1).  The
+            // task's lane compacts its own slots; the agents' lanes then take their abandonment from the task's `gone` mask --
+            // no scatter through LDS: an agent's counters live in its own lane.
+            uint64_t gone = 0ull;
+            if (any_drop) {
+                uint32_t spread = 0, q1 = 0;
+                bool prev = false;
 #pragma unroll
-            for (int j = 0; j < M; j++) {
-                spread |= (av[j] <= thr) ? (1u << j) : 0u;                       // :262-265
-                const bool e = !prev && (now - av[j] >= mwt);                    // :268-271 remove-while-iterating
-                q1 |= e ? (1u << j) : 0u;
-                prev = e;
-            }
-            const uint32_t drop = le0 ? spread : q1;
-            const uint64_t ids = r.ids;
-            uint64_t nids = 0;
-            int k = 0;
-#pragma unroll
-            for (int j = 0; j < M; j++) if (j < n) {
-                const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
-                if (drop & (1u << j)) {
-                    const uint32_t nth_ = atomicAdd(&S.ainfo()[id], 1u << 16) >> 16;   // abandoned_agent.append :265/:271
-                    if (nth_ < (uint32_t)AB_CAP) S.ablog()[id * AB_CAP + nth_] = (uint16_t)lt;
-                    else { const uint32_t ci = (uint32_t)(id * S.T() + lt); atomicAdd((uint32_t*)S.abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
-                    if (S.cur()[id] == lt) atomicAnd(&S.ainfo()[id], ~A_MEMBER);
-                } else {
-                    nids |= (uint64_t)id << (8 * k);
-                    S.marr()[k * CT + lt] = av[j];
-                    k++;
+                for (int j = 0; j < M; j++) {
+                    spread |= (av[j] <= thr) ? (1u << j) : 0u;                   // :262-265
+                    const bool e = !prev && (now - av[j] >= mwt);                // :269, skipping the element after a removal
+                    q1 |= e ? (1u << j) : 0u;
+                    prev = e;
                 }
+                const uint32_t drop = le0 ? spread : q1;
+                const uint64_t ids = r.ids;
+                uint64_t nids = 0ull;
+                int k = 0;
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    const uint64_t id = (ids >> (8 * j)) & 0xFF;
+                    const bool listed = j < n, leaves = listed && ((drop >> j) & 1u);
+                    gone |= leaves ? (1ull << id) : 0ull;
+                    if (listed && !leaves) { nids |= id << (8 * k); S.marr()[k * CT + lt] = av[j]; k++; }
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) if (j >= k && j < n) S.marr()[j * CT + lt] = __builtin_nan("");   // vacated slots
+                r.ids = nids; r.lm &= ~gone;
+                r.nab += (uint32_t)(n - k);                                      // abandoned_agent.append :265/:271
+                nn = k;
             }
-            for (int j = k; j < n; j++) S.marr()[j * CT + lt] = __builtin_nan("");
-            r.ids = nids;
-            S.tnab()[lt] += (uint32_t)(n - k);
-            nn = k;
+            uint64_t todo = dmask;
+            do {
+                const int t = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint64_t g = rl(gone, t);
+                if ((g >> lane) & 1ull) {                                        // this lane's agent was dropped by task t
+                    const uint32_t nth_ = r.ai >> 16;
+                    r.ai += 1u << 16;
+                    if (nth_ < (uint32_t)AB_CAP) r.ab[nth_] = (uint16_t)t;
+                    else { const uint32_t ci = (uint32_t)(la * S.T() + t); atomicAdd((uint32_t*)S.abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
+                    if (r.cur == t) r.ai &= ~A_MEMBER;                           // no longer `agent in current_task['members']` :230
+                }
+            } while (todo);
         }
         const uint32_t info_i = ((info | (ok ? T_FEAS : 0u)) & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
         const uint32_t info_f = info | ((now >= tfin) ? T_FIN : 0u);             // :273-274
@@ -152,13 +173,7 @@ struct Fast {
         r.ti = info; r.ts = nts; r.tf = ntf;
         if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
         const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
-        const bool dropped = __ballot(any_drop) != 0ull;
         WSYNC();
-        if (dropped) {
-            // the removal path counted the abandonment in the agent's LDS flag word and cleared its membership bit there: take both
-            const uint32_t w = S.ainfo()[la];
-            r.ai = (r.ai & 0xFFFFu & (w | ~A_MEMBER)) | (w & 0xFFFF0000u);
-        }
         if (all_feasible) {                                                      // depot :277-280
             if ((r.ai & A_INDEPOT) && now >= r.arr) r.ai |= A_RETURNED;
         }
@@ -199,8 +214,9 @@ struct Fast {
         const bool unfinished = !(info & T_FEAS) && status > 0;                  // :199
         const uint64_t bm = __ballot(unfinished) & tm;
         if constexpr (OBS) {
-            const uint32_t depot_bit = bm ? 1u : 0u;                             // worker.py:58-61
-            const uint8_t mv = isD ? (uint8_t)depot_bit : (uint8_t)(unfinished ? 0 : 1);   // :193
+            // :193 per task; the depot's byte is False iff every task is masked (worker.py:58-61)
+            const bool zero = isD ? (bm == 0ull) : unfinished;
+            const uint8_t mv = zero ? 0 : 1;
             const float g0 = (float)status, g1 = (float)(info & 0xFF), g2 = (float)r.dur;
             const float g3 = (float)(r.tx - lx), g4 = (float)(r.ty - ly);        // :185-188
             if (inT || isD) { *mkp = mv; tkrow[0] = g0; tkrow[1] = g1; tkrow[2] = g2; tkrow[3] = g3; tkrow[4] = g4; }
@@ -227,6 +243,7 @@ struct Fast {
         int rlen = glen - 1;
         uint64_t mm = 1ull << leader, mlist = (uint64_t)(uint32_t)leader;
         int nm = 1;
+        int mypos = 0;                                                           // this lane's position in the step's member list
         const int tl = action ? action - 1 : DL;                                 // lane that owns the target
         if (action == 0) {                                                       // vacancy = len(group) :327 (Q9)
             mm |= rest; nm += rlen; rlen = 0;
@@ -241,52 +258,43 @@ struct Fast {
                 rest &= ~(1ull << f); rlen--;                                    // :332-333
                 mm |= 1ull << f;
                 mlist |= (uint64_t)(uint32_t)f << (8 * nm);
+                // v_writelane: lane f takes its list position
+                // (gfx9 allows one SGPR on the constant bus: the value goes there, the lane select through M0)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypos) : "s"(nm), "s"(f));   // (M0 is reserved: the compiler never keeps a value in it)
                 nm++;
             }
         }
         const double tx_ = rl(r.tx, tl), ty_ = rl(r.ty, tl);
-        // agent_step :300-324 on all lanes (fp64 work with few active lanes is 4x slower), state changes on the members' lanes
-        const double d = dist2(r.ax, r.ay, tx_, ty_);
-        const double arrv = now + over_velocity(d);                              // :315,:318
+        // agent_step :300-324 on ALL lanes (fp64 VALU work with fewer than 16 active lanes is 4x slower on gfx950; the asm
+        // statement keeps the compiler from sinking the chain into the members-only block below)
+        double d = dist2(r.ax, r.ay, tx_, ty_);
+        double arrv = now + over_velocity(d);                                    // :315,:318
+        asm volatile("" : "+v"(d), "+v"(arrv));
         const bool mem = (mm >> lane) & 1ull;
-        uint64_t ids = 0; uint32_t kinfo = 0; int n = 0;
-        int mypos = 0;
-        bool relisted = false;
+        uint64_t ids = 0ull; uint32_t kinfo = 0; int n = 0;
+        int slot = 0;
         if (action) {
             // :321-322 members.append unless already listed (Q4: a re-joining agent keeps its slot, its arrival is overwritten)
             kinfo = (uint32_t)__builtin_amdgcn_readlane((int)r.ti, tl);
             ids = rl(r.ids, tl);
             n = (kinfo >> 16) & 0xFF;
-            // position of this lane in the step's ordered member list; is it already listed in the task?
-            const uint64_t pat = 0x0101010101010101ull * (uint64_t)(uint32_t)lane;
-            const uint64_t xm = mlist ^ pat;
-            uint64_t zm = (xm - 0x0101010101010101ull) & ~xm & 0x8080808080808080ull;
-            zm &= (1ull << (8 * nm)) - 1ull;                                     // nm <= 5
-            mypos = (__ffsll((unsigned long long)zm) - 1) >> 3;
-            const uint64_t xi = ids ^ pat;
-            uint64_t zi = (xi - 0x0101010101010101ull) & ~xi & 0x8080808080808080ull;
-            zi &= (1ull << (8 * n)) - 1ull;                                      // n <= 5
-            relisted = __ballot(mem && zi != 0ull) != 0ull;
-        }
-        int slot = n + mypos;
-        if (relisted) {
-            // rare (Q4): walk the members in order as the reference does; every lane learns its own slot
-            uint64_t ids2 = ids;
-            int n2 = n;
-            for (int j = 0; j < nm; j++) {
-                const int m = (int)((mlist >> (8 * j)) & 0xFF);
-                const uint64_t x = ids2 ^ (0x0101010101010101ull * (uint64_t)(uint32_t)m);
-                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-                z &= (n2 >= 8) ? ~0ull : ((1ull << (8 * n2)) - 1ull);
-                int pos;
-                if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
-                else { pos = n2++; ids2 |= (uint64_t)(uint32_t)m << (8 * pos); }
-                if (lane == m) slot = pos;
+            slot = n + mypos;
+            if (rl(r.lm, tl) & mm) {
+                // rare (Q4): walk the members in order as the reference does; every member's lane learns its own slot
+                for (int j = 0; j < nm; j++) {
+                    const int m = (int)((mlist >> (8 * j)) & 0xFF);
+                    const uint64_t x = ids ^ (0x0101010101010101ull * (uint64_t)(uint32_t)m);
+                    uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+                    z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
+                    int pos;
+                    if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                    else { pos = n++; ids |= (uint64_t)(uint32_t)m << (8 * pos); }
+                    if (lane == m) slot = pos;
+                }
+            } else {
+                ids |= mlist << (8 * n);                                         // bytes above n are always zero
+                n += nm;
             }
-            ids = ids2; n = n2;
-        } else if (action) {
-            ids |= mlist << (8 * n);                                             // bytes above n are always zero
-            n += nm;
         }
         if (mem) {
             r.td += d;                                                           // :317
@@ -294,10 +302,9 @@ struct Fast {
             r.ax = tx_; r.ay = ty_;                                              // :320
             r.cur = action - 1;                                                  // :314
             r.ai = (r.ai & ~(A_GRP | A_MEMBER)) | (action == 0 ? A_INDEPOT : A_MEMBER);
-            S.cur()[la] = action - 1; S.ainfo()[la] = r.ai;                      // the member-removal path reads them by index
             if (action) S.marr()[slot * CT + tl] = arrv;
         }
-        if (action && lane == tl) { r.ids = ids; r.ti = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
+        if (action && lane == tl) { r.ids = ids; r.lm |= mm; r.ti = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
         WSYNC();
         task_update(r, now, P.mwt, lane);                                        // worker.py:74
         agent_update(r, now, P.mwt);                                             // worker.py:76
@@ -311,7 +318,7 @@ struct Fast {
     __device__ __forceinline__ bool next_event(R& r, HdrRegs& h, const KP& P, int lane) const {
         if (h.now >= P.max_time) return false;
         const double ndv = inA ? r.nd : __builtin_nan("");
-        const double tmin = wave_nanmin(ndv);                                    // :287
+        const double tmin = wave_nanmin_n<CA>(ndv);                              // :287
         if (!(tmin == tmin)) return false;
         h.now = tmin;                                                            // worker.py:49
         const bool dec = (ndv == tmin);                                          // :288 exact ==
@@ -331,9 +338,9 @@ struct Fast {
             uint32_t gid = 0;
             int g = 0;
             for (;;) {
-                const double mxv = wave_nanmin(todo ? r.ax : __builtin_nan(""));
+                const double mxv = wave_nanmin_n<CA>(todo ? r.ax : __builtin_nan(""));
                 if (!(mxv == mxv)) break;
-                const double myv = wave_nanmin((todo && r.ax == mxv) ? r.ay : __builtin_nan(""));
+                const double myv = wave_nanmin_n<CA>((todo && r.ax == mxv) ? r.ay : __builtin_nan(""));
                 g++;
                 if (todo && r.ax == mxv && r.ay == myv) { gid = (uint32_t)g; todo = false; }
             }
@@ -406,7 +413,13 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
                 need_adv = true;
             }
         }
-        if (need_adv) { S.advance(h, P, lane, row PH_PASS); need_adv = false; }
+        if (need_adv) {
+            S.advance(h, P, lane, row PH_PASS);
+            need_adv = false;
+            // wave-uniform by construction; tell the compiler so (scalar branches in the fast loop)
+            h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+            h.empty_passes = uni(h.empty_passes);
+        }
         if (!(h.flags & DCM_FLAG_DONE) && left != 0) {
             WSYNC();
             f.reload(r);
