@@ -86,6 +86,10 @@ struct Sim {
     static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
     static constexpr int NTC = CT ? (CT + 63) / 64 : 0;       // task lane chunks (0 = runtime)
     static constexpr bool EXACT = (CA != 0) && !RS;
+    // <CA, CT, true> with more than one task chunk (<128,256,true>): the template only BOUNDS the sizes -- agent-mask words and
+    // lane-chunk trip counts are constants, loops unrolled -- while the record keeps the batch's own layout Lay{pA,pT} (a
+    // Lay{128,256} image would be 30 KB per env whatever the batch needs); every mid-size shape shares this one instantiation
+    static constexpr bool RL = RS && (CT > WAVE);
     int rA, rT;           // this env's own sizes (ignored by the exact instantiation)
     int pA, pT;           // record layout dims (read by the <0,0> instantiation only)
     unsigned char* base;  // record base (LDS in the env kernels)
@@ -103,12 +107,12 @@ struct Sim {
     struct XY { double x[IRB ? NTC : 1], y[IRB ? NTC : 1]; };
     // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
     // BASELINE batch be resident); every other kernel trades it for more resident workgroups
-    static constexpr bool SCR_IN_LDS = (CA != 0 && Lay{CA, CT}.lds_bytes() <= 10240);   // 16 workgroups per CU still fit
+    static constexpr bool SCR_IN_LDS = (CA != 0 && !RL && Lay{CA, CT}.lds_bytes() <= 10240);   // 16 workgroups per CU still fit
 
     __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }
     __device__ __forceinline__ int T() const { return EXACT ? CT : rT; }
-    __device__ __forceinline__ Lay L() const { return Lay{CA ? CA : pA, CT ? CT : pT}; }
-    __device__ __forceinline__ int PT() const { return CT ? CT : pT; }     // pitch of the [M][T] member-arrival slots
+    __device__ __forceinline__ Lay L() const { return Lay{(CA && !RL) ? CA : pA, (CT && !RL) ? CT : pT}; }
+    __device__ __forceinline__ int PT() const { return (CT && !RL) ? CT : pT; }     // pitch of the [M][T] member-arrival slots
     // batch dims (shapes of the output arrays) given the kernel's (A,T) arguments
     __device__ __forceinline__ static int BA(int A) { return EXACT ? CA : A; }
     __device__ __forceinline__ static int BT(int T) { return EXACT ? CT : T; }
@@ -211,7 +215,7 @@ struct Sim {
                 copy16_in(base, rec, l.mut_bytes(), lane);
                 copy16_in(base + l.tx(), rec + l.tdur(), align16(8 * CT), lane);
             }
-        } else if constexpr (CA != 0 && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
+        } else if constexpr (CA != 0 && !RL && ALL) copy16_in_all<Lay{CA, CT}.rec_bytes(), NT>(base, rec, lane);
         else copy16_in(base, rec, L().rec_bytes(), lane);
     }
 
@@ -1542,8 +1546,9 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
 // ---------------------------------------------------------------------------------- host side
 // Instantiations: the three BASELINE shapes exactly; <20,50,runtime sizes> for every other shape (uniform or ragged) inside
 // the reference's training range A <= 20, T <= 50 (parameters.py:15-16); <64,64,runtime sizes> for the remaining one-chunk
-// shapes (A <= 64, T <= 64: one lane per agent / task); <0,0> for the rest.
-#define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(64, 64, true); X(50, 200, false); X(100, 500, false); X(0, 0, false)
+// shapes (A <= 64, T <= 64: one lane per agent / task); <128,256,runtime sizes and layout> for the mid sizes (generate_env
+// takes any size, env/task_env.py:57-65); <0,0> for the rest.
+#define FOR_EACH_INSTANCE(X) X(20, 50, false); X(20, 50, true); X(64, 64, true); X(50, 200, false); X(100, 500, false); X(128, 256, true); X(0, 0, false)
 // one-chunk layouts: the register-resident persistent kernel (rollout_fast.hpp)
 #define FOR_EACH_FAST(X) X(20, 50, false); X(20, 50, true); X(64, 64, true)
 #define DISPATCH_ENV(env, CALL)                                                                        \
@@ -1554,6 +1559,7 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
         else if (e_->L.A == 64 && e_->L.T == 64) { CALL(64, 64, true); }                               \
         else if (exact_ && e_->A == 50 && e_->T == 200) { CALL(50, 200, false); }                      \
         else if (exact_ && e_->A == 100 && e_->T == 500) { CALL(100, 500, false); }                    \
+        else if (e_->A <= 128 && e_->T <= 256) { CALL(128, 256, true); }   /* mid sizes: bounded trip counts, own layout */ \
         else { CALL(0, 0, false); }                                                                    \
     } while (0)
 // kernel arguments every env kernel starts with: batch dims, layout dims
