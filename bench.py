@@ -10,7 +10,8 @@ One bench "step" = one pass of the hot path over one batch.
 --config 4 = BASELINE.json configs[3]: 65 536 envs of 50A/200T in total, sharded over the N ranks by contiguous blocks
     (strong scaling), one episode per env per pass.
 --config 5 = BASELINE.json configs[4]: route replay (execute_by_route) of 100A/500T instances with dynamic task arrivals,
-    8192 envs in total sharded over the N ranks (strong scaling); a step of this config = one agent_step call of the
+    32 768 envs in total sharded over the N ranks (strong scaling; BASELINE does not fix the count: chosen so that the 8-GPU
+    shard still holds four waves per SIMD); a step of this config = one agent_step call of the
     replay.  Preset routes are synthetic (the reference ships routes for 20A/50T only).  --visibility initial,batch,period,cap
     selects another dynamic-arrival schedule than the reference's hard-coded 20,20,10,100 (under which tasks 101..500 never
     appear): reported as a separate workload, never as the config-5 number.
@@ -66,7 +67,8 @@ CONFIGS = {
     # name: envs, agents, tasks, episodes per pass, scaling, label, kernel
     "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]", kernel="k_rollout_random"),
     "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]", kernel="k_rollout_random"),
-    "5": dict(envs=8192, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
+    # 32 768 envs in total: the 8-GPU shard is 4096 envs = 4 waves per SIMD (at 8192 in total it was one wave per SIMD: pure latency)
+    "5": dict(envs=32768, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
 }
 AUTO_STREAM_CANDIDATES = (4, 2, 1)   # --streams 0: pick the fastest of these in an untimed calibration before the warm-up
 
@@ -156,10 +158,15 @@ def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seco
                 single_thread_rate=n0 / dt0)
 
 
-def lockstep_kernel_probe(A, T, dev, B=65536, n=40, warm=8):
+def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
     """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
     decision: the HBM roofline of this path is quoted on it, at a batch that fills the machine, HIP events around
-    dcm_step only, device-side random policy; `warm` untimed steps first (the GPU has idled through the CPU baseline)."""
+    dcm_step only, device-side random policy; `warm` untimed steps first.  Runs right after the timed region, BEFORE the
+    CPU baseline: after seconds of host-only work the GPU has clocked down, and 40 steps (~10 ms) are over before it is
+    back at speed (BENCH_r03: 167 us median there against 137-143 us on a busy GPU).
+    `frac` prices a launch with the ALGORITHMIC bytes W (the kernel skips clean sections, so this can exceed what
+    HBM delivers); `traffic_frac` is the MEASURED HBM traffic of the committed profile of the same batch over the same time --
+    the physical utilisation."""
     env = BatchedTaskEnv(B, A, T, device=str(dev)).load_instances(**generate_batch(B, A, T, base_seed=0))
     obs = env.reset(env_seeds(0, 0, B))
     for _ in range(warm):
@@ -177,7 +184,9 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=40, warm=8):
     out = {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
            "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
            "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9), "algorithmic_bytes_per_launch": B * Wb,
-           "traffic": c.get("hbm_bytes_per_launch") if c else None, "counters_source": c.get("source") if c else None,
+           "traffic": c.get("hbm_bytes_per_launch") if c else None,
+           "traffic_frac": (c["hbm_bytes_per_launch"] / (ms * 1e-3) / HBM_PEAK_BYTES_PER_S) if c and c.get("hbm_bytes_per_launch") else None,
+           "counters_source": c.get("source") if c else None,
            "rocprof_avg_launch_us": c.get("avg_launch_us") if c else None,
            "stale": staleness(c, _lib.build_id()) if c else None}
     env.close()
@@ -413,7 +422,7 @@ def main():
                         "note": "SURVEY §8(d) pricing; the record never leaves LDS, see roofline.hbm for real traffic"}
     what = (f"route replay with dynamic task arrivals (visibility schedule initial,batch,period,cap = {visibility}"
             + (", the reference's constants" if visibility == REFERENCE_VISIBILITY else ", GENERALISED: not the reference's constants")
-            + "), synthetic preset routes") if replay else "random-policy rollout"
+            + f"), synthetic preset routes over tasks 1..{min(T, visibility[3])} (the tasks that can ever become visible)") if replay else "random-policy rollout"
     if static_replay:
         what = "route replay WITHOUT dynamic arrivals (reactive_planning False: not BASELINE configs[4]), synthetic preset routes over all tasks"
     out = {
@@ -436,19 +445,18 @@ def main():
                    "self_launched": os.environ.get("DCM_SELF_LAUNCHED") is not None},
         "roofline": roof,
     }
-    if ctx.world == 1 and not args.no_cpu_baseline:
-        sb = subs[0]
-        inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
-        if replay:
-            out["cpu_baseline"] = cpu_baseline_replay(inst, np.concatenate([x.routes for x in subs]),
-                                                      np.concatenate([x.route_len for x in subs]), A, visibility,
-                                                      reactive=not static_replay)
-        else:
-            out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
     if ctx.world == 1 and not args.no_lockstep_probe and not replay:
         for sb in subs:
             sb.env.close()
         out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        sb = subs[0]
+        inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
+        if replay:
+            # (route arrays of the sub-batches can differ in their cap: the baseline samples the first sub-batch's envs)
+            out["cpu_baseline"] = cpu_baseline_replay(sb.inst, sb.routes, sb.route_len, A, visibility, reactive=not static_replay)
+        else:
+            out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
     print(json.dumps(out), flush=True)
     ctx.shutdown()
 

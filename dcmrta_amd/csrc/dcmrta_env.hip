@@ -1418,6 +1418,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
 }
 
 #include "rollout_fast.hpp"
+#include "step_fast.hpp"
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
@@ -1640,7 +1641,8 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
 #undef SET_ATTR
 #define SET_FAST(CA, CT, RS)                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
-    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    (void)hipFuncSetAttribute((const void*)k_step_fast<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     FOR_EACH_FAST(SET_FAST);
 #undef SET_FAST
     (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1757,6 +1759,22 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (!actions) return fail(DCM_ERR_INVALID, "dcm_step: null actions");
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
+#ifndef DCM_NO_FAST_STEP
+    // The plain call shape on a one-chunk layout: the register-resident step (step_fast.hpp); same contract, same results.
+    if (env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
+        mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
+#define CALL(CA, CT, RS)                                                                                             \
+    hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
+                       env->state, actions, agents_out, tasks_out, mask_out, leader_out, active_out, env->summary, env->ablog,  \
+                       env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
+        const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
+        if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
+        else { CALL(64, 64, true); }
+#undef CALL
+        LAUNCH_OK();
+        return DCM_OK;
+    }
+#endif
 #define CALL(CA, CT, RS)                                                                                             \
     hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \

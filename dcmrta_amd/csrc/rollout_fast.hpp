@@ -25,7 +25,9 @@
 // Reference restated: worker.py:45-87 (loop), env/task_env.py:161-342 (the functions named at each block below).
 #pragma once
 
-template <int CA, int CT, bool RS, bool OBS>
+// TRK (lockstep kernel): the fast path records which task sections of the record it has changed (Sim::DIRTY_* bits), so that
+// the write-back can skip the others
+template <int CA, int CT, bool RS, bool OBS, bool TRK = false>
 struct Fast {
     using SimT = Sim<CA, CT, RS, false>;
     using AMask = typename SimT::AMask;
@@ -34,6 +36,7 @@ struct Fast {
     static constexpr Lay L{CA, CT};
 
     SimT S;
+    mutable uint32_t dirty = 0;                        // TRK only
     uint64_t am, tm;                                   // lanes that own an agent / a task (wave-uniform masks)
     // per-lane constants
     bool inA, inT, isD;
@@ -153,6 +156,7 @@ struct Fast {
                 r.nab += (uint32_t)(n - k);                                      // abandoned_agent.append :265/:271
                 nn = k;
             }
+            if constexpr (TRK) dirty |= SimT::DIRTY_ALL & ~SimT::DIRTY_TIMES;   // slots compacted: every arrival row, ids, counts
             uint64_t todo = dmask;
             do {
                 const int t = __ffsll((unsigned long long)todo) - 1;
@@ -172,6 +176,7 @@ struct Fast {
         info = feas0 ? info_f : info_i;
         r.ti = info; r.ts = nts; r.tf = ntf;
         if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
+        if constexpr (TRK) { if (__ballot(becomes && inT)) dirty |= SimT::DIRTY_TIMES; }
         const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
         WSYNC();
         if (all_feasible) {                                                      // depot :277-280
@@ -227,20 +232,28 @@ struct Fast {
     // ------------------------------------------------------------------------------ one decision
     // worker.py:54-76: leader, observation, uniform-random valid action, TaskEnv.step + agent_step (env/task_env.py:300-342),
     // task_update, agent_update.  Returns the number of agents of the group that have not acted yet.
-    __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp) const {
-        const double now = h.now;
-        // leader (protocol slot 0)
-        const uint64_t gm = __ballot((int)((r.ai >> 8) & 0xFFu) == h.cur_group) & am;
+    // worker.py:54 -- the deciding agent of the current group (protocol slot 0); -1: the group is empty (unreachable)
+    __device__ __forceinline__ int pick_leader(const R& r, const HdrRegs& h, uint64_t k1, uint64_t& gm) const {
+        gm = __ballot((int)((r.ai >> 8) & 0xFFu) == h.cur_group) & am;
         const int glen = __popcll(gm);
-        if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return 0; }    // unreachable: groups are never empty
-        const int leader = nth(gm, below((uint32_t)(k1 >> 32), glen));
-        const uint64_t bm = observe(r, now, leader, agrow, tkrow, mkp);
+        if (glen == 0) return -1;
+        return nth(gm, below((uint32_t)(k1 >> 32), glen));
+    }
+    __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp) const {
+        uint64_t gm;
+        const int leader = pick_leader(r, h, k1, gm);
+        if (leader < 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return 0; }    // unreachable: groups are never empty
+        const uint64_t bm = observe(r, h.now, leader, agrow, tkrow, mkp);
         // uniform-random valid action (protocol slot 1)
         const int nv = __popcll(bm);
         const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
-        // TaskEnv.step :326-342
+        return apply(r, h, P, lane, k1, gm, leader, action);
+    }
+    // TaskEnv.step :326-342 with the leader's (valid: unmasked task or depot) action, then task_update / agent_update
+    __device__ __forceinline__ int apply(R& r, const HdrRegs& h, const KP& P, int lane, uint64_t k1, uint64_t gm, int leader, int action) const {
+        const double now = h.now;
         uint64_t rest = gm & ~(1ull << leader);                                  // :328
-        int rlen = glen - 1;
+        int rlen = __popcll(gm) - 1;
         uint64_t mm = 1ull << leader, mlist = (uint64_t)(uint32_t)leader;
         int nm = 1;
         int mypos = 0;                                                           // this lane's position in the step's member list
@@ -279,6 +292,7 @@ struct Fast {
             ids = rl(r.ids, tl);
             n = (kinfo >> 16) & 0xFF;
             slot = n + mypos;
+            if constexpr (TRK) dirty |= SimT::DIRTY_IDS | ((rl(r.lm, tl) & mm) ? 0x3Eu : ((((1u << nm) - 1u) << (n + 1)) & 0x3Eu));   // ids + the arrival rows written
             if (rl(r.lm, tl) & mm) {
                 // rare (Q4): walk the members in order as the reference does; every member's lane learns its own slot
                 for (int j = 0; j < nm; j++) {

@@ -1,0 +1,155 @@
+// step_fast.hpp -- the lockstep kernel of the one-chunk layouts for the PLAIN call shape of dcm_step: no injected leader /
+// followers, no route log, all five outputs, grouping on (what a policy in the loop calls: worker.py:54-76 once per env).
+// Included by dcmrta_env.hip after rollout_fast.hpp.
+//
+// k_step runs the general Sim<> code on the LDS image: ~500 VALU + ~650 scalar + ~100 LDS instructions per step in a dozen dependent
+// LDS round trips, and at a machine-filling batch its rate is (resident workgroups) / (workgroup lifetime), not HBM bandwidth
+// (profiles/r03_lockstep: 53 % of the wave time parked on s_waitcnt).  Here the step itself runs on the register-resident
+// simulator of rollout_fast.hpp -- record -> LDS (coalesced), lane-owned fields -> registers, one decision with the HOST's
+// action, registers -> LDS, dirty sections -> HBM -- whenever that action is one the device policy could have taken (the depot,
+// or an unmasked task: every action of a mask-respecting policy).  Anything else (a masked or out-of-range action, an event at
+// which nobody can decide, the end of an episode, auto-reset) takes the general code on the same LDS image, exactly as k_step.
+// The observation of the next decision is built from the registers when they hold the env, from the LDS image otherwise.
+#pragma once
+
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE, 4) void k_step_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
+                                                   float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
+                                                   uint8_t* active_out, double* summary, uint16_t* ablog, uint32_t mode,
+                                                   const int32_t* sizes, unsigned char* gscr, uint32_t max_episodes, double* retlog,
+                                                   int retcap) {
+    const int e = env_of_workgroup(), lane = threadIdx.x;
+    int eA, eT;
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+    using F = Fast<CA, CT, RS, true, true>;
+    using SimT = typename F::SimT;
+    using AMask = typename SimT::AMask;
+    SimT S{eA, eT, PA, PT, smem, nullptr};
+    const Lay L = S.L();
+    S.scr = gscr + (size_t)e * L.scratch_bytes();
+    const int BA = S.BA(A), BT = S.BT(T);
+    unsigned char* rec = state + (size_t)e * L.rec_bytes();
+    double* row = summary + (size_t)e * 8;
+    const int act_in = actions[e];                 // requested first: its latency hides behind the record copy
+    typename SimT::XY xy;
+    S.template load_record<false>(rec, lane, xy);
+    S.set_ablog(ablog, e, BA, BT, lane);
+    S.set_retlog(retlog, retcap, e, lane);
+    if (lane == 0) *S.dirty() = 0;
+    WSYNC();
+    HdrRegs h = load_hdr(smem);
+    F f{S};
+    f.init(lane);
+    typename F::R r;
+    bool regs = false;       // the registers hold the env: agent arrays / member ids / abandonment counts of the LDS image are stale
+    constexpr uint32_t ERR = DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE;
+    const bool was_active = !(h.flags & DCM_FLAG_DONE);
+    PH_DECL;
+    if (was_active) {
+        f.load_consts(r);
+        f.reload(r);
+        const uint64_t k1 = key1(h.seed, h.d);
+        // an action the device policy could have taken?  (env/task_env.py:192-200 + worker.py:58-61: an unmasked task; the depot
+        // is simulated the same way whether or not it is masked: the whole co-located group returns)
+        bool plain = act_in == 0;
+        if (act_in >= 1 && act_in <= S.T()) {
+            const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)r.ti, act_in - 1);
+            plain = !(ik & T_FEAS) && (int)(int8_t)((ik >> 8) & 0xFF) > 0;
+        }
+        if (plain) {
+            uint64_t gm;
+            const int leader = f.pick_leader(r, h, k1, gm);
+            if (leader < 0) h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE;     // unreachable: groups are never empty
+            else {
+                const int rlen = f.apply(r, h, P, lane, k1, gm, leader, act_in);
+                h.d += 1;
+                regs = true;
+                if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
+                    if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group
+                    else if (!f.next_event(r, h, P, lane)) {                      // worker.py:85 -> :45
+                        f.flush(r);
+                        regs = false;
+                        S.advance(h, P, lane, row PH_PASS, false, true);
+                    }
+                }
+            }
+        } else {
+            // masked / out-of-range action: simulated (or refused, DCM_PARAM_STRICT_MASK) by the general code, see apply_and_advance
+            AMask gm;
+            const int leader = S.pick_leader(h, lane, -1, k1, gm, false);
+            if (leader >= 0)
+                S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0,
+                                    false, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true, &xy);
+        }
+        // wave-uniform by construction; tell the compiler so
+        h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+        h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
+        // DCM_PARAM_AUTO_RESET: the episode has just ended -> start the next one from the loaded instance (see k_step); an episode
+        // only ever ends in the general code, so the LDS image is current here
+        if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) && !(h.flags & ERR) &&
+            (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
+            S.reset_state(h, lane);
+            if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
+            S.advance(h, P, lane, row PH_PASS, false);
+            h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+            h.empty_passes = uni(h.empty_passes);
+        }
+        if (regs) f.flush(r);
+        WSYNC();
+        store_hdr(h, lane);
+        WSYNC();
+        // write back what the step can have changed (see k_step)
+        const uint32_t dm = uni(*S.dirty()) | f.dirty;
+        auto put = [&](uint32_t lo, uint32_t hi) {
+            lo &= ~15u; hi = (hi + 15u) & ~15u;
+            copy16(rec + lo, smem + lo, hi - lo, lane);
+        };
+        const uint32_t Tn = (uint32_t)S.PT();
+        put(0, L.tb());                                                               // header + agent arrays
+        if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                            // time_start, time_finish
+        if ((dm & 0x3Eu) == 0x3Eu) put(L.marr(), L.mids());
+        else {
+#pragma unroll
+            for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+        }
+        if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
+        put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());            // status words (+ abandonment counts)
+    }
+    // mask + observation of the next decision (worker.py:57-68), fused
+    WSYNC();
+    float* ag = agents_out + (size_t)e * 6 * BA;
+    float* tk = tasks_out + (size_t)e * 5 * (BT + 1);
+    uint8_t* mk = mask_out + (size_t)e * (BT + 1);
+    int leader = -1;
+    if (!(h.flags & DCM_FLAG_DONE)) {
+        const uint64_t k1n = key1(h.seed, h.d);
+        if (regs) { uint64_t gm; leader = f.pick_leader(r, h, k1n, gm); }
+        else { AMask gm; leader = S.pick_leader(h, lane, -1, k1n, gm, false); }
+    }
+    if (leader >= 0) {
+        // rows built in LDS and stored as contiguous runs for grids that fill the machine several times over (see k_step)
+        const uint32_t need = 24u * (uint32_t)S.A() + 21u * ((uint32_t)S.T() + 1u) + 16u;
+        const bool staged = gridDim.x >= 8192u && L.tinfo() - L.marr() >= need;
+        float* sag = (float*)(smem + L.marr());
+        float* stk = sag + 6 * S.A();
+        uint8_t* smk = (uint8_t*)(stk + 5 * (S.T() + 1));
+        float* oag = staged ? sag : ag;
+        float* otk = staged ? stk : tk;
+        uint8_t* omk = staged ? smk : mk;
+        if (regs) f.observe(r, h.now, leader, oag + 6 * f.la, otk + (f.inT ? 5 * (lane + 1) : 0), omk + (f.inT ? lane + 1 : 0));
+        else S.observe(h, lane, leader, oag, otk, omk, xy);
+        if (staged) {
+            WSYNC();
+            for (int i = lane; i < 6 * S.A(); i += WAVE) ag[i] = sag[i];
+            for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) tk[i] = stk[i];
+            for (int i = lane; i <= S.T(); i += WAVE) mk[i] = smk[i];
+        }
+    } else {
+        S.write_inactive_obs(lane, ag, tk, mk);
+    }
+    if constexpr (RS) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
+    if (lane == 0) {
+        leader_out[e] = leader;
+        active_out[e] = leader >= 0 ? 1 : 0;
+    }
+}

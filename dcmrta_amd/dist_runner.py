@@ -42,17 +42,27 @@ class ShardedRunner:
 
     # ------------------------------------------------------------------ weights
     def _bcast_module(self, module, src):
-        params = [p.data for p in module.state_dict().values() if torch.is_tensor(p)]
-        flat = torch.cat([p.reshape(-1).to(torch.float32) for p in params]) if params else torch.zeros(0)
-        if self.ctx.active:
+        """state_dict of `module` from rank `src` to every rank: one flat buffer per dtype (no conversion: fp64 parameters and
+        integer / bool buffers travel bit for bit), the source rank's own tensors are not touched."""
+        if not self.ctx.active:
+            return
+        groups = {}
+        for p in module.state_dict().values():
+            if torch.is_tensor(p):
+                groups.setdefault(p.dtype, []).append(p.data)
+        for dtype, params in groups.items():
+            wire = torch.uint8 if dtype == torch.bool else dtype
+            flat = torch.cat([p.reshape(-1).to(wire) for p in params])
             buf = flat.cpu() if self.ctx.backend == "gloo" else flat
             dist.broadcast(buf, src=src)
-            flat = buf.to(flat.device)
-        o = 0
-        for p in params:
-            n = p.numel()
-            p.copy_(flat[o:o + n].view_as(p).to(p.dtype))
-            o += n
+            if self.ctx.rank == src:
+                continue
+            flat = buf.to(params[0].device)
+            o = 0
+            for p in params:
+                n = p.numel()
+                p.copy_(flat[o:o + n].view_as(p).to(dtype))
+                o += n
 
     def broadcast_weights(self, src=0):
         """Rank `src`'s policy and baseline weights on every rank (one flat buffer per network)."""
@@ -125,14 +135,24 @@ class ShardedRunner:
         n = torch.tensor([float(n_local)], dtype=torch.float64, device=self.ctx._coll_device())
         if self.ctx.active:
             dist.all_reduce(n)
-        for p in module.parameters():
+        params = list(module.parameters())
+        for p in params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            if self.ctx.active:
-                g = p.grad.cpu() if self.ctx.backend == "gloo" else p.grad
-                dist.all_reduce(g)
-                if g is not p.grad:
-                    p.grad.copy_(g)
+        if self.ctx.active and params:       # one collective over one flat buffer per dtype, not one per parameter
+            groups = {}
+            for p in params:
+                groups.setdefault(p.grad.dtype, []).append(p.grad)
+            for grads in groups.values():
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                buf = flat.cpu() if self.ctx.backend == "gloo" else flat
+                dist.all_reduce(buf)
+                flat = buf.to(grads[0].device)
+                o = 0
+                for g in grads:
+                    g.copy_(flat[o:o + g.numel()].view_as(g))
+                    o += g.numel()
+        for p in params:
             p.grad.div_(float(n))
         return int(n)
 

@@ -39,7 +39,7 @@ class EnvError(RuntimeError):
 class BatchedRunner:
     def __init__(self, metaAgentID=0, n_envs=256, device="cuda:0", net_factory=None, base_seed=0, max_steps=None, gamma=1.0,
                  rollout_precision="fp32", check_every=8, use_graph=True, cache_shapes=8, buckets="auto", episode_stride=None,
-                 env_offset=0, strict_mask=False, twin_rollout="auto", tune_gemms=False, gemm_tuning_file=None):
+                 env_offset=0, strict_mask=None, twin_rollout="auto", tune_gemms=False, gemm_tuning_file=None):
         """rollout_precision "bf16" / "fp16": the rollouts (sampled, greedy twin, evaluation) run a low-precision shadow
         of localNetwork (net.rollout_copy(dtype), refreshed after every weight update); needs a net that offers
         rollout_copy / sync_rollout_copy (the stand-in does).  max_steps: capacity of the experience record in batched
@@ -61,8 +61,11 @@ class BatchedRunner:
         # (dist.shard_range) use a common stride >= the largest shard (ray_compat) or the whole budget plus their shard offset
         # (dist_runner), so that no two of them ever play the same instance
         # strict_mask: freeze (and report, EnvError) an env whose policy picks a masked task instead of simulating the action
-        # the way the reference's TaskEnv.step does
-        self.strict_mask = bool(strict_mask)
+        # the way the reference's TaskEnv.step does.  None (default): strict for the sampled / greedy rollouts of job() and
+        # testing() -- a masked pick there can only come from a broken policy (NaN logits of a low-precision shadow make argmax
+        # return the NaN index) and must not be fed to REINFORCE silently -- and the reference's semantics (any action is
+        # simulated) for run_test, whose argmax(logp.exp() * ~mask) can legitimately land on a masked index (worker.py:140)
+        self.strict_mask = None if strict_mask is None else bool(strict_mask)
         # twin_rollout: job() plays the sampled episode and its greedy self-critic twin (worker.py:89) of every env in ONE batch
         # of 2 n_envs (rows [0, B) sample, rows [B, 2B) take the argmax of the same net on the same instance and seed): one
         # policy forward, one graph replay and one tail per decision instead of two -- what pays when the loop is launch-bound
@@ -125,14 +128,15 @@ class BatchedRunner:
         return self._shadow if self._shadow is not None else self.localNetwork
 
     # ------------------------------------------------------------------ env management
-    def _slot(self, A, T, individual_selection=False, n_envs=None):
+    def _slot(self, A, T, individual_selection=False, n_envs=None, strict=True):
         """Env + captured graphs of one batch shape.  Training draws a new (agents_num, tasks_num) every round
-        (driver.py:114-115), so the last few shapes are kept."""
-        key = (A, T, bool(individual_selection), int(n_envs or self.B))
+        (driver.py:114-115), so the last few shapes are kept.  strict: what strict_mask=None resolves to for this use."""
+        strict = bool(strict) if self.strict_mask is None else self.strict_mask
+        key = (A, T, bool(individual_selection), int(n_envs or self.B), strict)
         slot = self._cache.get(key)
         if slot is None:
             slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection,
-                                           strict_mask=self.strict_mask), graphs={})
+                                           strict_mask=strict), graphs={})
             self._cache[key] = slot
             while len(self._cache) > self._cache_shapes:
                 _, old = self._cache.popitem(last=False)
@@ -164,10 +168,11 @@ class BatchedRunner:
         raise ValueError(mode)
 
     def _check_flags(self, env, what):
-        """The device freezes an env whose action is masked / out of range (BAD_ACTION), would overfill a task (OVERFLOW)
-        or whose injected leader is not deciding (BAD_LEADER) and never computes its terminal row: refuse to average NaN
-        rewards into the batch (the reference would step onto the masked task; its policy contract never does,
-        attention.py:74-76).  Truncated episodes (zero-decider guard) are counted and reported."""
+        """The device freezes an env whose action is out of range or -- on a strict handle: every rollout of job() / testing()
+        unless strict_mask=False was asked for -- masked (BAD_ACTION), that would list more members than the handle's slots
+        (OVERFLOW), or whose injected leader is not deciding (BAD_LEADER), and never computes its terminal row: refuse to
+        average NaN rewards into the batch.  On a non-strict handle (run_test) a masked action is simulated like the
+        reference's TaskEnv.step does (env/task_env.py:326-342).  Truncated episodes (zero-decider guard) are counted."""
         flags = env.status()["flags"]
         bad = (flags & (_lib.FLAG_BAD_ACTION | _lib.FLAG_OVERFLOW | _lib.FLAG_BAD_LEADER | _lib.FLAG_BAD_INSTANCE)) != 0
         n_bad = int(bad.sum())
@@ -187,7 +192,10 @@ class BatchedRunner:
         if mode == "twin":
             # 1 for the sampling rows, 0 for the greedy ones: argmax(logp - gate * log(q)) is the exponential race on the
             # former and the plain argmax on the latter; `rows` = the env indices a compacted graph runs the policy on
-            gate = slot.setdefault("twin_gate", torch.cat([torch.ones(env.B // 2, 1), torch.zeros(env.B - env.B // 2, 1)]).to(env.device))
+            gate = slot.get("twin_gate")
+            if gate is None:      # built once per slot, on the device (no host tensor + synchronous copy per job)
+                gate = slot["twin_gate"] = torch.cat([torch.ones(env.B // 2, 1, device=env.device),
+                                                      torch.zeros(env.B - env.B // 2, 1, device=env.device)])
 
             def policy(obs, rows=None):
                 logp = net(obs.tasks, obs.agents, obs.mask)
@@ -363,7 +371,7 @@ class BatchedRunner:
             raise ValueError("run_test: give n_agents (agents per env) or a per-env `n_agents` array in `instances`")
         A = int(n_agents if n_agents is not None else np.max(instances["n_agents"]))
         ss = env_seeds(self.base_seed, 0, N) if seeds is None else np.asarray(seeds, dtype=np.uint64)
-        slot = self._slot(A, T, individual_selection=individual_selection, n_envs=N)
+        slot = self._slot(A, T, individual_selection=individual_selection, n_envs=N, strict=False)
         env = slot["env"]
         env.load_instances(**instances)
         net = self._rollout_net()
