@@ -16,7 +16,8 @@ no-ops (the device applied them), next_decision / get_unique_group report the de
 computed, and current_time only moves forward when the caller commits it (`env.current_time = t`,
 worker.py:49), which keeps the `current_time < MAX_TIME` loop test of worker.py:45 on the previous event's time
 exactly like the reference (quirk Q7).  It is a compatibility surface for the reference's call pattern, not a
-general re-implementation of every call order; use BatchedTaskEnv for throughput.
+general re-implementation of every call order: a caller that commits a time other than the event time next_decision() returned
+gets a ValueError instead of stale answers.  Use BatchedTaskEnv for throughput.
 
 Differences a caller can observe: observations are the fp32 values the policy receives (the reference returns
 fp64 and casts at worker.py:62,64); followers are drawn by the keyed choice protocol instead of numpy's RNG.
@@ -139,6 +140,14 @@ class TaskEnv:
 
     @current_time.setter
     def current_time(self, t):
+        # The reference recomputes task_update / agent_update from whatever time the caller has set (env/task_env.py:245-281);
+        # here they were applied on the device at the event time next_decision() reports.  Committing any OTHER time would make
+        # the following (no-op) task_update / agent_update silently stale: refuse it instead.
+        self._sync()
+        if not self._done and float(t) != self._now and float(t) != self._visible_time:
+            raise ValueError(f"TaskEnv.current_time = {float(t)!r}: only the event time returned by next_decision() "
+                             f"({self._now!r}) can be committed; the device env advances time itself (use BatchedTaskEnv / the "
+                             f"reference's call order worker.py:45-87)")
         self._visible_time = float(t)
 
     @property
@@ -195,7 +204,9 @@ class TaskEnv:
         want = set(int(a) for a in agents)
         return [[a for a in g if a in want] for g in self._pending_groups() if any(a in want for a in g)]
 
-    def task_update(self):  # applied on the device inside dcm_reset / dcm_step (worker.py:50,74)
+    def task_update(self):
+        """Applied on the device inside dcm_reset / dcm_step at the reference's call sites (worker.py:50,74): a no-op here,
+        valid because the only times a caller can commit are the device's own event times (current_time setter)."""
         return []
 
     def agent_update(self):  # idem (worker.py:51,76)

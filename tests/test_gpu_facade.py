@@ -203,3 +203,17 @@ def test_reset_with_reference_dicts(gpu_device, golden_dir):
     assert (a.agents_num, a.tasks_num) == (A, 50) and np.array_equal(a.depot["location"], inst["depot"][i])
     b = TaskEnv.from_arrays(A, inst["depot"][i], inst["task_xy"][i], inst["req"][i], inst["dur"][i], device=gpu_device)
     assert episode(a) == episode(b)
+
+
+def test_committing_a_foreign_time_is_refused(gpu_device):
+    """task_update / agent_update are no-ops of the facade (the device applied them at its own event time): a caller that sets
+    another current_time -- after which the reference would recompute from that time, env/task_env.py:245-281 -- gets an
+    exception, not stale answers."""
+    from dcmrta_amd.task_env import TaskEnv
+    env = TaskEnv((5, 5), (8, 8), seed=3, device=gpu_device)
+    ids, t = env.next_decision()
+    env.current_time = t                      # the reference's call order (worker.py:49): fine
+    env.task_update(); env.agent_update()
+    with pytest.raises(ValueError, match="only the event time"):
+        env.current_time = t + 1.25
+    assert env.current_time == t
