@@ -1419,6 +1419,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
 
 #include "rollout_fast.hpp"
 #include "step_fast.hpp"
+#include "rollout_fast_mc.hpp"
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
@@ -1645,6 +1646,8 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     (void)hipFuncSetAttribute((const void*)k_step_fast<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     FOR_EACH_FAST(SET_FAST);
 #undef SET_FAST
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast_mc<50, 200, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast_mc<50, 200, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_get_agents, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = h;
@@ -1807,6 +1810,17 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
         else { CALL(64, 64, true); }
 #undef CALL
 #undef CALLF
+        LAUNCH_OK();
+        return DCM_OK;
+    }
+    // BASELINE configs[3], 50A/200T exactly: the multi-chunk register-resident kernel (rollout_fast_mc.hpp)
+    if (!env->sizes && env->A == 50 && env->T == 200 && env->L.A == 50 && env->L.T == 200 && (all_obs || no_obs)) {
+#define CALLM(OBS)                                                                                                    \
+    hipLaunchKernelGGL((k_rollout_fast_mc<50, 200, OBS>), GRID(env), (FastM<50, 200, OBS>::LDS_BYTES), (hipStream_t)stream, \
+                       DIMS(env), env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
+        if (all_obs) { CALLM(true); } else { CALLM(false); }
+#undef CALLM
         LAUNCH_OK();
         return DCM_OK;
     }
