@@ -11,9 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCMRTA_HIP_LIB") or os.path.join(_HERE, "libdcmrta_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FOLLOWER_COLS = 4
 MAX_MEMBERS = 5
+MAX_MEMBERS_WIDE = 8     # DCM_PARAM_WIDE_MEMBERS handles
+PARAM_NO_GROUPING, PARAM_AUTO_RESET, PARAM_STRICT_MASK, PARAM_WIDE_MEMBERS = 1, 2, 4, 8
 MAX_AGENTS = 128
 MAX_TASKS = 1023
 

@@ -42,7 +42,7 @@ def _ptr(t):
 
 class BatchedTaskEnv:
     def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
-                 individual_selection=False, auto_reset=False, auto_reset_episodes=0, strict_mask=False):
+                 individual_selection=False, auto_reset=False, auto_reset_episodes=0, strict_mask=False, member_cap=5):
         self._h = None
         self._lib = _lib.load()
         self.device = torch.device(device)
@@ -59,7 +59,13 @@ class BatchedTaskEnv:
         # batch stays full; summary() holds each env's last finished episode, episodes() counts them
         # strict_mask: freeze an env whose host-supplied action is on a masked task (DCM_PARAM_STRICT_MASK) instead of
         # simulating it like the reference's TaskEnv.step does
-        flags = (1 if individual_selection else 0) | (2 if auto_reset else 0) | (4 if strict_mask else 0)
+        # member_cap: member slots per task -- 5 (COALITION_SIZE, parameters.py:17) or, for a mask-ignoring policy (worker.py:140) or
+        # max_coalition_size > 5 (env/task_env.py:71), 8 (DCM_PARAM_WIDE_MEMBERS: larger records, runtime-size kernels, no replay)
+        if not 1 <= int(member_cap) <= _lib.MAX_MEMBERS_WIDE:
+            raise DcmError(f"member_cap must be in 1..{_lib.MAX_MEMBERS_WIDE}")
+        self.member_cap = _lib.MAX_MEMBERS if int(member_cap) <= _lib.MAX_MEMBERS else _lib.MAX_MEMBERS_WIDE
+        flags = (1 if individual_selection else 0) | (2 if auto_reset else 0) | (4 if strict_mask else 0) | \
+                (_lib.PARAM_WIDE_MEMBERS if self.member_cap > _lib.MAX_MEMBERS else 0)
         # auto_reset_episodes: an env stops restarting after that many finished episodes (0 = never)
         p = DcmParams(self.B, self.A, self.T, idx, self.max_waiting_time, self.max_time, flags, int(auto_reset_episodes))
         h = C.c_void_p()
@@ -101,7 +107,7 @@ class BatchedTaskEnv:
 
     # ------------------------------------------------------------------ instances / reset
     def load_instances(self, depot, task_xy, req, dur, n_agents=None, n_tasks=None):
-        """depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] int in 1..5, dur[B,T] f64 (numpy or torch).
+        """depot[B,2] f64, task_xy[B,T,2] f64, req[B,T] int in 1..member_cap, dur[B,T] f64 (numpy or torch).
 
         n_agents[B] / n_tasks[B] (host ints, 1..A / 1..T) make the batch ragged: env e is an (n_agents[e], n_tasks[e])
         env (TaskEnv with tuple ranges, env/task_env.py:58-65), rows beyond its sizes in the arrays are ignored and its
@@ -118,8 +124,8 @@ class BatchedTaskEnv:
             if nt.shape != (B,) or na.shape != (B,):
                 raise DcmError(f"n_agents / n_tasks must be int[{B}]")
             req_np[np.arange(T)[None, :] >= nt[:, None]] = 1      # ignored rows: anything valid
-        if req_np.min() < 1 or req_np.max() > _lib.MAX_MEMBERS:
-            raise DcmError(f"req must be int[{B},{T}] with values in 1..{_lib.MAX_MEMBERS}")
+        if req_np.min() < 1 or req_np.max() > self.member_cap:
+            raise DcmError(f"req must be int[{B},{T}] with values in 1..{self.member_cap} (member_cap of this env)")
         d = self._dev(depot, torch.float64)
         xy = self._dev(task_xy, torch.float64)
         rq = self._dev(req, torch.int32)
@@ -251,8 +257,8 @@ class BatchedTaskEnv:
         return o
 
     def task_members(self):
-        """int16[B,T,5]: task['members'] of every task in list order, -1 padded (env/task_env.py:80)."""
-        out = torch.empty((self.B, self.T, _lib.MAX_MEMBERS), dtype=torch.int16, device=self.device)
+        """int16[B,T,member_cap]: task['members'] of every task in list order, -1 padded (env/task_env.py:80)."""
+        out = torch.empty((self.B, self.T, self.member_cap), dtype=torch.int16, device=self.device)
         with torch.cuda.device(self.device):
             check(self._lib.dcm_get_members(self._h, _ptr(out), self._stream()))
         return out

@@ -58,6 +58,7 @@ __host__ __device__ constexpr size_t side_bytes(int B, int A, int T) {
 // Record layout as a function of (A,T); see DESIGN.md §3.  All sections 8-byte aligned.
 struct Lay {
     int A, T;
+    int C = M;   // member slots per task: DCM_MAX_MEMBERS, or DCM_MAX_MEMBERS_WIDE for a DCM_PARAM_WIDE_MEMBERS handle
     __host__ __device__ constexpr uint32_t ax() const { return 64; }                 // f64[A] location x
     __host__ __device__ constexpr uint32_t ay() const { return 64 + 8 * A; }         // f64[A] location y
     __host__ __device__ constexpr uint32_t arr() const { return 64 + 16 * A; }       // f64[A] arrival_time[-1]
@@ -68,11 +69,11 @@ struct Lay {
     __host__ __device__ constexpr uint32_t tb() const { return 64 + 48 * A; }
     __host__ __device__ constexpr uint32_t ts() const { return tb(); }               // f64[T] time_start
     __host__ __device__ constexpr uint32_t tf() const { return tb() + 8 * T; }       // f64[T] time_finish
-    __host__ __device__ constexpr uint32_t marr() const { return tb() + 16 * T; }    // f64[M][T] member arrivals
-    __host__ __device__ constexpr uint32_t mids() const { return tb() + 56 * T; }    // u64[T] ordered member ids
-    __host__ __device__ constexpr uint32_t tinfo() const { return tb() + 64 * T; }   // u32[T]
-    __host__ __device__ constexpr uint32_t tnab() const { return tb() + 68 * T; }    // u32[T] len(abandoned_agent)
-    __host__ __device__ constexpr uint32_t mut_bytes() const { return align16(tb() + 72 * T); }
+    __host__ __device__ constexpr uint32_t marr() const { return tb() + 16 * T; }    // f64[C][T] member arrivals
+    __host__ __device__ constexpr uint32_t mids() const { return marr() + 8 * C * T; }   // u64[T] ordered member ids (one byte each, C <= 8)
+    __host__ __device__ constexpr uint32_t tinfo() const { return mids() + 8 * T; }  // u32[T]
+    __host__ __device__ constexpr uint32_t tnab() const { return tinfo() + 4 * T; }  // u32[T] len(abandoned_agent)
+    __host__ __device__ constexpr uint32_t mut_bytes() const { return align16(tnab() + 4 * T); }
     __host__ __device__ constexpr uint32_t tx() const { return mut_bytes(); }        // f64[T] task x (instance)
     __host__ __device__ constexpr uint32_t ty() const { return mut_bytes() + 8 * T; }
     __host__ __device__ constexpr uint32_t tdur() const { return mut_bytes() + 16 * T; }
@@ -94,6 +95,9 @@ struct Lay {
     __host__ __device__ constexpr uint32_t lds_bytes() const { return lds_rec() + scratch_bytes(); }     // record + scratch in LDS
 };
 static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
+static_assert(Lay{20, 50}.mids() == Lay{20, 50}.tb() + 56 * 50 && Lay{20, 50}.mut_bytes() == align16(Lay{20, 50}.tb() + 72 * 50), "5 member slots: the canonical record");
+constexpr int MW = DCM_MAX_MEMBERS_WIDE;
+static_assert(MW <= 8, "member ids are one byte each of a 64-bit word");
 
 struct KP {
     double mwt;       // max_waiting_time

@@ -81,8 +81,10 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 // not copied into LDS at all: the kernel works on the marr section of the env's own HBM record (one wave owns the record; a
 // wave's global accesses are issued and served in order, so it sees its own stores, and the section is read only at the head of
 // task_update's chain and by the terminal metrics).  The sections behind it move up by MSH bytes in the LDS image.
-template <int CA, int CT, bool RS, bool MG = false>
+// MC: member slots per task (5; 8 on a DCM_PARAM_WIDE_MEMBERS handle, which always runs the <0,0> instantiation).
+template <int CA, int CT, bool RS, bool MG = false, int MC = M>
 struct Sim {
+    static_assert(MC == M || (MC == MW && CA == 0 && !MG), "wide member slots: runtime-size instantiation only");
     static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
     static constexpr int NTC = CT ? (CT + 63) / 64 : 0;       // task lane chunks (0 = runtime)
     static constexpr bool EXACT = (CA != 0) && !RS;
@@ -95,7 +97,7 @@ struct Sim {
     unsigned char* base;  // record base (LDS in the env kernels)
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
     double* gm = nullptr; // MG: the marr section of this env's HBM record
-    static constexpr uint32_t MSH = MG ? 40u * (uint32_t)CT : 0u;   // = Lay::mids() - Lay::marr()
+    static constexpr uint32_t MSH = MG ? 8u * (uint32_t)MC * (uint32_t)CT : 0u;   // = Lay::mids() - Lay::marr()
     // Exact multi-chunk shapes (50A/200T, 100A/500T): the task coordinates -- read-only instance data that only the task's own
     // lane and, for the chosen task, the whole wave ever read -- live in two registers per lane chunk (struct XY, owned by the
     // kernel and handed to observe / apply_and_advance) instead of 16 bytes per task of LDS.  The LDS image of a 50A/200T env
@@ -111,7 +113,7 @@ struct Sim {
 
     __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }
     __device__ __forceinline__ int T() const { return EXACT ? CT : rT; }
-    __device__ __forceinline__ Lay L() const { return Lay{(CA && !RL) ? CA : pA, (CT && !RL) ? CT : pT}; }
+    __device__ __forceinline__ Lay L() const { return Lay{(CA && !RL) ? CA : pA, (CT && !RL) ? CT : pT, MC}; }
     __device__ __forceinline__ int PT() const { return (CT && !RL) ? CT : pT; }     // pitch of the [M][T] member-arrival slots
     // batch dims (shapes of the output arrays) given the kernel's (A,T) arguments
     __device__ __forceinline__ static int BA(int A) { return EXACT ? CA : A; }
@@ -299,9 +301,10 @@ struct Sim {
     static constexpr bool INC = (CT == 0 || CT > WAVE);
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + aux_off() + 8); }
     __device__ __forceinline__ float* wake() const { return (float*)(base + aux_off() + 48); }    // f32[PT], INC kernels only
-    // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..M member-arrival row j,
-    // bit 6 member ids, bit 7 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
-    static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_IDS = 1u << 6, DIRTY_NAB = 1u << 7, DIRTY_ALL = 0xFFu;
+    // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..MC member-arrival row j,
+    // bit 12 member ids, bit 13 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
+    static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_ROWS = ((1u << MC) - 1u) << 1, DIRTY_IDS = 1u << 12, DIRTY_NAB = 1u << 13,
+                              DIRTY_ALL = DIRTY_TIMES | DIRTY_ROWS | DIRTY_IDS | DIRTY_NAB;
     __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + aux_off() + 24); }
     __device__ __forceinline__ void task_update(const HdrRegs& h, const KP& P, int lane, int only = -1, bool track = false) const {
         const double now = h.now, mwt = P.mwt;
@@ -314,14 +317,14 @@ struct Sim {
             const int n = (info >> 16) & 0xFF;                               // :250
             // Unused slots (j >= n) hold NaN in LDS (reset / compaction keep that invariant): v_max/v_min ignore
             // them and every comparison against them is false, so no per-slot validity predicate is needed.
-            double av[M];
+            double av[MC];
 #pragma unroll
-            for (int j = 0; j < M; j++) av[j] = marr()[j * PT_ + t];         // :251
+            for (int j = 0; j < MC; j++) av[j] = marr()[j * PT_ + t];        // :251
             const double tfin = tf()[t], dur = tdur()[t];
             const int status = req - n;                                      // :252
             double mx = av[0], mn = av[0];
 #pragma unroll
-            for (int j = 1; j < M; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
+            for (int j = 1; j < MC; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
             const bool le0 = status <= 0;                                    // :254
             const bool ok = le0 && (mx - mn <= mwt);                         // :255
             const double thr = mx - mwt;                                     // :262
@@ -337,7 +340,7 @@ struct Sim {
                     uint32_t spread = 0, q1 = 0;
                     bool prev = false;
 #pragma unroll
-                    for (int j = 0; j < M; j++) {
+                    for (int j = 0; j < MC; j++) {
                         spread |= (av[j] <= thr) ? (1u << j) : 0u;           // :262-265
                         // :268-271 iterates task['members'] while removing from it: after a removal the element
                         // that slides into the freed slot is skipped by the list iterator (quirk Q1).
@@ -350,7 +353,7 @@ struct Sim {
                     uint64_t nids = 0;
                     int k = 0;
 #pragma unroll
-                    for (int j = 0; j < M; j++) if (j < n) {
+                    for (int j = 0; j < MC; j++) if (j < n) {
                         const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
                         if (drop & (1u << j)) {
                             // abandoned_agent.append(member) :265/:271; the agent stops being listed at `t`
@@ -472,17 +475,20 @@ struct Sim {
             const double ab = (double)tnab()[t] * mwt;
             // all M member slots are read back to back (unused ones hold NaN, which v_max_f64 ignores) instead of walking
             // the n valid ones with one LDS round trip each
-            double av[M];
+            double av[MC];
 #pragma unroll
-            for (int j = 0; j < M; j++) av[j] = marr()[j * PT_ + t];
+            for (int j = 0; j < MC; j++) av[j] = marr()[j * PT_ + t];
             double mx = av[0];
 #pragma unroll
-            for (int j = 1; j < M; j++) mx = nanmax2(mx, av[j]);             // np.max(arrival) :350
+            for (int j = 1; j < MC; j++) mx = nanmax2(mx, av[j]);            // np.max(arrival) :350
             mx = n ? mx : 0.;
             const bool feas = info & T_FEAS;
-            double s = 0.;
+            double s = 0., term[MC];
 #pragma unroll
-            for (int j = 0; j < M; j++) { const double term = feas ? mx - av[j] : now - av[j]; s = (j < n) ? s + term : s; }   // :351 / :354
+            for (int j = 0; j < MC; j++) { term[j] = feas ? mx - av[j] : now - av[j]; s = (j < n) ? s + term[j] : s; }   // :351 / :354
+            if constexpr (MC >= 8) {   // np.sum of exactly eight terms is numpy's unrolled pairwise block, not a running sum
+                if (n == 8) s = ((term[0] + term[1]) + (term[2] + term[3])) + ((term[4] + term[5]) + (term[6] + term[7]));
+            }
             tw()[t] = s + ab;                                                // :351-357
             tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
             const uint64_t ids = mids()[t];
@@ -795,7 +801,7 @@ struct Sim {
             mids()[t] = 0;
             ts()[t] = 0.0; tf()[t] = 0.0;
 #pragma unroll
-            for (int j = 0; j < M; j++) marr()[j * PT_ + t] = __builtin_nan("");   // empty member slots
+            for (int j = 0; j < MC; j++) marr()[j * PT_ + t] = __builtin_nan("");  // empty member slots
         });
         {   // abandoned_agent = [] :131.  The count table (HBM, 2*A*T bytes) only holds the abandonments beyond the log's
             // 16 per agent, so it needs clearing only after an episode in which some agent overflowed its log
@@ -963,7 +969,7 @@ struct Sim {
                 const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
                 nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
             }
-            if (nf > M - 1 || nf > rlen) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+            if (nf > MC - 1 || nf > rlen || (nfol_in >= 0 && nf > DCM_FOLLOWER_COLS)) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                    // :331 choice without replacement
                 int f;
@@ -1037,7 +1043,7 @@ struct Sim {
                 int pos;
                 if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
                 else {
-                    if (n >= M) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+                    if (n >= MC) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
                     pos = n++;
                     ids |= (uint64_t)(uint32_t)m << (8 * pos);                // bytes above n are always zero
                 }
@@ -1104,13 +1110,13 @@ __device__ __forceinline__ int env_of_workgroup() {
     return x * q + (x < r ? x : r) + i;
 }
 
-__global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, int PT, unsigned char* state, const double* depot,
+__global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, int PT, int PC, unsigned char* state, const double* depot,
                                                         const double* task_xy, const int32_t* req, const double* dur,
                                                         const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    const Lay L{PA, PT};                                       // input arrays are pitched by the batch dims (A,T)
+    const Lay L{PA, PT, PC};                                   // input arrays are pitched by the batch dims (A,T)
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     double *tx = (double*)(rec + L.tx()), *ty = (double*)(rec + L.ty()), *td = (double*)(rec + L.tdur());
     uint32_t* ti = (uint32_t*)(rec + L.tinfo());
@@ -1119,11 +1125,11 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, i
         tx[t] = task_xy[((size_t)e * T + t) * 2];
         ty[t] = task_xy[((size_t)e * T + t) * 2 + 1];
         td[t] = dur[(size_t)e * T + t];
-        // requirements outside 1..DCM_MAX_MEMBERS do not fit the member slots (the reference takes any max_coalition_size,
+        // requirements outside 1..(member slots of the handle) do not fit the member slots (the reference takes any max_coalition_size,
         // env/task_env.py:71): the env is marked and stays frozen instead of simulating something else
         const int32_t r = req[(size_t)e * T + t];
-        bad = bad || r < 1 || r > DCM_MAX_MEMBERS;
-        ti[t] = (uint32_t)(r < 1 ? 1 : r > DCM_MAX_MEMBERS ? DCM_MAX_MEMBERS : r);
+        bad = bad || r < 1 || r > PC;
+        ti[t] = (uint32_t)(r < 1 ? 1 : r > PC ? PC : r);
     }
     bad = __any(bad);
     if (lane == 0) {
@@ -1134,18 +1140,18 @@ __global__ __launch_bounds__(WAVE) void k_load_instances(int A, int T, int PA, i
     }
 }
 
-template <int CA, int CT, bool RS>
+template <int CA, int CT, bool RS, int MC = M>
 __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP P, unsigned char* state, const uint64_t* seeds,
                                                double* summary, uint16_t* ablog, uint32_t mode, const int32_t* sizes,
                                                unsigned char* gscr) {
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
+    Sim<CA, CT, RS, false, MC> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    typename Sim<CA, CT, RS>::XY xy;
+    typename Sim<CA, CT, RS, false, MC>::XY xy;
     S.load_record(rec, lane, xy);
     WSYNC();
     S.set_ablog(ablog, e, S.BA(A), S.BT(T), lane);
@@ -1165,18 +1171,19 @@ __global__ __launch_bounds__(WAVE) void k_reset(int A, int T, int PA, int PT, KP
     copy16(rec, smem, L.mut_bytes(), lane);
 }
 
-template <int CA, int CT, bool RS>
+template <int CA, int CT, bool RS, int MC = M>
 __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, unsigned char* state, float* agents_out, float* tasks_out,
                                                  uint8_t* mask_out, int32_t* leader_out, uint8_t* active_out,
                                                  const int32_t* leader_in, const int32_t* sizes, uint32_t mode) {
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};   // (observe never reaches the terminal metrics: no scratch)
+    using SimT = Sim<CA, CT, RS, false, MC>;
+    SimT S{eA, eT, PA, PT, smem, nullptr};   // (observe never reaches the terminal metrics: no scratch)
     const Lay L = S.L();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    typename Sim<CA, CT, RS>::XY xy;
+    typename SimT::XY xy;
     S.load_record(rec, lane, xy);
     WSYNC();
     HdrRegs h = load_hdr(smem);
@@ -1186,7 +1193,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     int leader = -1;
     const uint32_t flags0 = h.flags;
     if (!(h.flags & DCM_FLAG_DONE)) {
-        typename Sim<CA, CT, RS>::AMask gm;
+        typename SimT::AMask gm;
         leader = S.pick_leader(h, lane, leader_in ? leader_in[e] : -1, key1(h.seed, h.d), gm, (mode & DCM_PARAM_NO_GROUPING) != 0);
     }
     if (leader >= 0) S.observe(h, lane, leader, ag, tk, mk, xy);
@@ -1199,7 +1206,7 @@ __global__ __launch_bounds__(WAVE) void k_observe(int A, int T, int PA, int PT, 
     }
 }
 
-template <int CA, int CT, bool RS>
+template <int CA, int CT, bool RS, int MC = M>
 __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
                                               const int32_t* leader_in, const int32_t* nfol_in, const int16_t* fol_in,
                                               float* agents_out, float* tasks_out, uint8_t* mask_out,
@@ -1209,8 +1216,9 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    Sim<CA, CT, RS> S{eA, eT, PA, PT, smem, nullptr};
-    using AMask = typename Sim<CA, CT, RS>::AMask;
+    using SimT = Sim<CA, CT, RS, false, MC>;
+    SimT S{eA, eT, PA, PT, smem, nullptr};
+    using AMask = typename SimT::AMask;
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     const int BA = S.BA(A), BT = S.BT(T);
@@ -1223,7 +1231,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     const int nf = nfol_in ? nfol_in[e] : -1;
         // (plain loads, not the non-temporal ones of the persistent kernel: with the record read AND rewritten every launch the
     //  default L2 policy measured 5.5 % faster at 65 536 envs, same at 4096)
-    typename Sim<CA, CT, RS>::XY xy;
+    typename SimT::XY xy;
     S.template load_record<false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
@@ -1251,7 +1259,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
                 if (log.len) for (int a = lane; a < eA; a += WAVE) log.len[(size_t)e * BA + a] = 0;
                 S.reset_state(h, lane);
-                if (lane == 0) *S.dirty() = Sim<CA, CT, RS>::DIRTY_ALL;
+                if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
                 S.advance(h, P, lane, summary + (size_t)e * 8 PH_PASS, (mode & DCM_PARAM_NO_GROUPING) != 0);
                 PHK_MARK(3);                       // auto-reset: reset_state + first event
             }
@@ -1272,14 +1280,14 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         };
         const uint32_t Tn = (uint32_t)S.PT();
         put(0, L.tb());                                                               // header + agent arrays
-        if (dm & Sim<CA, CT, RS>::DIRTY_TIMES) put(L.ts(), L.marr());                 // time_start, time_finish
-        if ((dm & 0x3Eu) == 0x3Eu) put(L.marr(), L.mids());
+        if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                 // time_start, time_finish
+        if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
         else {
 #pragma unroll
-            for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+            for (int j = 0; j < MC; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
         }
-        if (dm & Sim<CA, CT, RS>::DIRTY_IDS) put(L.mids(), L.tinfo());
-        put(L.tinfo(), (dm & Sim<CA, CT, RS>::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
+        if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
+        put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
         PHK_MARK(5);                               // write-back (issue)
     }
     const bool want_obs = agents_out || tasks_out || mask_out || leader_out || active_out;
@@ -1333,7 +1341,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
 // 50A/200T instantiation wants 176 -- two waves per SIMD although its LDS image (10.9 KB with the member arrival times left in
 // the HBM record) would let twelve workgroups share a CU -- and with 168 (five spilled) it runs three: 8.65 -> 6.90 ms per
 // 8192-env launch.  Four (128 VGPRs, 47 spilled) measured slower again (7.15 ms).
-template <int CA, int CT, bool RS>
+template <int CA, int CT, bool RS, int MC = M>
 __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                         float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                         int64_t* steps_out, double* summary, uint16_t* ablog,
@@ -1342,7 +1350,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-    using SimT = Sim<CA, CT, RS, (CT > WAVE) && !RS>;   // member arrival times in the HBM record (MG) for the exact multi-chunk shapes
+    using SimT = Sim<CA, CT, RS, (CT > WAVE) && !RS, MC>;   // member arrival times in the HBM record (MG) for the exact multi-chunk shapes
     SimT S{eA, eT, PA, PT, smem, nullptr};
     using AMask = typename SimT::AMask;
     const Lay L = S.L();
@@ -1421,17 +1429,18 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
 #include "step_fast.hpp"
 #include "rollout_fast_mc.hpp"
 
-__global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, const unsigned char* state, int B, uint32_t* flags_out,
+__global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, int PC, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
     const int e = blockIdx.x * WAVE + threadIdx.x;
     if (e >= B) return;
-    const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{PA, PT}.rec_bytes());
+    const Hdr* h = (const Hdr*)(state + (size_t)e * Lay{PA, PT, PC}.rec_bytes());
     if (episodes_out) episodes_out[e] = (int32_t)h->episodes;
     if (flags_out) flags_out[e] = h->flags;
     if (dec_out) dec_out[e] = (int64_t)h->d;
     if (now_out) now_out[e] = h->now;
 }
 
+template <int MC>
 __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT, KP P, unsigned char* state, uint8_t* finished,
                                                    uint8_t* feasible, double* time_start, double* time_finish,
                                                    double* sum_wait, int32_t* status, int32_t* n_members,
@@ -1440,7 +1449,7 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    Sim<0, 0, false> S{eA, eT, PA, PT, smem, nullptr};
+    Sim<0, 0, false, false, MC> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
@@ -1463,6 +1472,7 @@ __global__ __launch_bounds__(WAVE) void k_get_tasks(int A, int T, int PA, int PT
     }
 }
 
+template <int MC>
 __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int PT, KP P, unsigned char* state, double* sum_wait,
                                                     double* travel_dist, double* next_decision, double* arrival,
                                                     double* x, double* y, uint8_t* returned, uint8_t* assigned,
@@ -1471,7 +1481,7 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int P
     const int e = blockIdx.x, lane = threadIdx.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    Sim<0, 0, false> S{eA, eT, PA, PT, smem, nullptr};
+    Sim<0, 0, false, false, MC> S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
     S.scr = gscr + (size_t)e * L.scratch_bytes();
     copy16_in(smem, state + (size_t)e * L.rec_bytes(), L.rec_bytes(), lane);
@@ -1496,13 +1506,13 @@ __global__ __launch_bounds__(WAVE) void k_get_agents(int A, int T, int PA, int P
     }
 }
 
-// task['members'] of every task, in list order (env/task_env.py:80): ids_out[B][T][DCM_MAX_MEMBERS], -1 padded
-__global__ void k_get_members(int T, int PA, int PT, const unsigned char* state, int B, int16_t* ids_out, const int32_t* sizes) {
+// task['members'] of every task, in list order (env/task_env.py:80): ids_out[B][T][member slots of the handle], -1 padded
+__global__ void k_get_members(int T, int PA, int PT, int PC, const unsigned char* state, int B, int16_t* ids_out, const int32_t* sizes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * T) return;
     const int e = (int)(i / T), t = (int)(i % T);
     const int eT = sizes ? sizes[2 * e + 1] : T;
-    const Lay L{PA, PT};
+    const Lay L{PA, PT, PC};
     const unsigned char* rec = state + (size_t)e * L.rec_bytes();
     uint64_t ids = 0;
     int n = 0;
@@ -1510,17 +1520,17 @@ __global__ void k_get_members(int T, int PA, int PT, const unsigned char* state,
         ids = ((const uint64_t*)(rec + L.mids()))[t];
         n = (int)((((const uint32_t*)(rec + L.tinfo()))[t] >> 16) & 0xFF);
     }
-    for (int j = 0; j < M; j++) ids_out[i * M + j] = (j < n) ? (int16_t)((ids >> (8 * j)) & 0xFF) : (int16_t)-1;
+    for (int j = 0; j < PC; j++) ids_out[i * PC + j] = (j < n) ? (int16_t)((ids >> (8 * j)) & 0xFF) : (int16_t)-1;
 }
 
 // task['abandoned_agent'] (env/task_env.py:89) as a dense count table: out[B][A][T] = number of times task t moved agent a to
 // its abandoned_agent list in the current episode = entries of the agent's abandonment log + the overflow count table
-__global__ __launch_bounds__(WAVE) void k_get_abandoned(int A, int T, int PA, int PT, const unsigned char* state,
+__global__ __launch_bounds__(WAVE) void k_get_abandoned(int A, int T, int PA, int PT, int PC, const unsigned char* state,
                                                        const uint16_t* ablog, uint16_t* out, const int32_t* sizes) {
     const int e = blockIdx.x, lane = threadIdx.x, B = gridDim.x;
     int eA, eT;
     env_dims<0, 0, false>(sizes, e, A, T, eA, eT);
-    const Lay L{PA, PT};
+    const Lay L{PA, PT, PC};
     const uint32_t* ainfo = (const uint32_t*)(state + (size_t)e * L.rec_bytes() + L.ainfo());
     const uint16_t* log_e = ablog + (size_t)e * A * AB_CAP;
     const uint16_t* cnt_e = (const uint16_t*)((const uint8_t*)(ablog + (size_t)B * A * AB_CAP) + (size_t)e * abcnt_pitch(A, T));
@@ -1557,7 +1567,8 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
     do {                                                                                               \
         const dcm_env* e_ = (env);                                                                     \
         const bool exact_ = !e_->sizes && e_->A == e_->L.A && e_->T == e_->L.T;                        \
-        if (e_->L.A == 20 && e_->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } } \
+        if (e_->L.C > M) { CALL(0, 0, false, MW); }   /* DCM_PARAM_WIDE_MEMBERS: eight member slots, runtime-size code */ \
+        else if (e_->L.A == 20 && e_->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } } \
         else if (e_->L.A == 64 && e_->L.T == 64) { CALL(64, 64, true); }                               \
         else if (exact_ && e_->A == 50 && e_->T == 200) { CALL(50, 200, false); }                      \
         else if (exact_ && e_->A == 100 && e_->T == 500) { CALL(100, 500, false); }                    \
@@ -1600,7 +1611,8 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     if (!h) return fail(DCM_ERR_INVALID, "dcm_create: out of host memory");
     h->p = *params;
     h->A = params->n_agents; h->T = params->n_tasks;
-    h->L = (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : (h->A <= 64 && h->T <= 64) ? Lay{64, 64} : Lay{h->A, h->T};
+    h->L = (params->flags & DCM_PARAM_WIDE_MEMBERS) ? Lay{h->A, h->T, MW}
+           : (h->A <= 20 && h->T <= 50) ? Lay{20, 50} : (h->A <= 64 && h->T <= 64) ? Lay{64, 64} : Lay{h->A, h->T};
     h->kp.mwt = params->max_waiting_time;
     h->kp.max_time = params->max_time;
     if (h->L.lds_rec() + align16(4u * (uint32_t)h->L.T) > 160 * 1024) { delete h; return fail(DCM_ERR_INVALID, "dcm_create: env record does not fit the 160 KiB LDS"); }
@@ -1631,7 +1643,10 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     const int dev_slot = params->device & 63;
     int lds = (int)(h->L.lds_rec() + align16(4u * (uint32_t)h->L.T));   // (+ the wake-up times of the multi-chunk layouts)
     if (h->L.lds_bytes() <= 10240) lds = (int)h->L.lds_bytes();           // persistent kernel of the small layouts: scratch in LDS
-    if (lds < lds_limit[dev_slot]) lds = lds_limit[dev_slot];
+    // (only when the limit really grows: the attribute calls of one host thread must not keep landing in another thread's
+    //  stream capture -- actors create handles for new batch shapes while others capture)
+    const bool grow = lds > lds_limit[dev_slot];
+    if (!grow) { *out = h; return DCM_OK; }
     lds_limit[dev_slot] = lds;
 #define SET_ATTR(CA, CT, RS)                                                                                             \
     (void)hipFuncSetAttribute((const void*)k_reset<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
@@ -1640,6 +1655,10 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     (void)hipFuncSetAttribute((const void*)k_rollout_random<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     FOR_EACH_INSTANCE(SET_ATTR);
 #undef SET_ATTR
+    (void)hipFuncSetAttribute((const void*)k_reset<0, 0, false, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_observe<0, 0, false, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_step<0, 0, false, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_rollout_random<0, 0, false, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 #define SET_FAST(CA, CT, RS)                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
@@ -1648,8 +1667,10 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
 #undef SET_FAST
     (void)hipFuncSetAttribute((const void*)k_rollout_fast_mc<50, 200, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)k_rollout_fast_mc<50, 200, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)k_get_tasks, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)k_get_agents, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_get_tasks<M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_get_agents<M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_get_tasks<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k_get_agents<MW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = h;
     return DCM_OK;
 }
@@ -1675,7 +1696,7 @@ int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy,
     CHECK_ENV(env);
     if (!depot || !task_xy || !req || !dur) return fail(DCM_ERR_INVALID, "dcm_load_instances: null array");
     if (env->sizes) { HIP_TRY(hipFree(env->sizes)); env->sizes = nullptr; }   // back to a uniform batch (hipFree synchronises)
-    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, depot, task_xy,
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->L.C, env->state, depot, task_xy,
                        req, dur, (const int32_t*)nullptr);
     LAUNCH_OK();
     env->loaded = true;
@@ -1699,7 +1720,7 @@ int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* t
     if (!env->sizes) HIP_TRY(hipMalloc((void**)&env->sizes, (size_t)2 * B * sizeof(int32_t)));
     HIP_TRY(hipMemcpyAsync(env->sizes, env->sizes_host.data(), (size_t)2 * B * sizeof(int32_t), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
-    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, depot, task_xy,
+    hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->L.C, env->state, depot, task_xy,
                        req, dur, (const int32_t*)env->sizes);
     LAUNCH_OK();
     env->loaded = true;
@@ -1711,8 +1732,8 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     CHECK_ENV(env);
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
-#define CALL(CA, CT, RS)                                                                                              \
-    hipLaunchKernelGGL((k_reset<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
+#define CALL(CA, CT, RS, ...)                                                                                         \
+    hipLaunchKernelGGL((k_reset<CA, CT, RS, ##__VA_ARGS__>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
                        env->state, seeds, env->summary, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch)
     DISPATCH_ENV(env, CALL);
 #undef CALL
@@ -1744,8 +1765,8 @@ int dcm_observe(dcm_env* env, float* agents_out, float* tasks_out, uint8_t* mask
                 uint8_t* active_out, const int32_t* leader_in, void* stream) {
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_observe: call dcm_reset first");
-#define CALL(CA, CT, RS)                                                                                                \
-    hipLaunchKernelGGL((k_observe<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env),            \
+#define CALL(CA, CT, RS, ...)                                                                                           \
+    hipLaunchKernelGGL((k_observe<CA, CT, RS, ##__VA_ARGS__>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env),            \
                        env->state, agents_out, tasks_out, mask_out, leader_out, active_out, leader_in,                  \
                        (const int32_t*)env->sizes, env->p.flags)
     DISPATCH_ENV(env, CALL);
@@ -1764,7 +1785,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
 #ifndef DCM_NO_FAST_STEP
     // The plain call shape on a one-chunk layout: the register-resident step (step_fast.hpp); same contract, same results.
-    if (env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
+    if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
         mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
 #define CALL(CA, CT, RS)                                                                                             \
     hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
@@ -1778,8 +1799,8 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
         return DCM_OK;
     }
 #endif
-#define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_step<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp,   \
+#define CALL(CA, CT, RS, ...)                                                                                        \
+    hipLaunchKernelGGL((k_step<CA, CT, RS, ##__VA_ARGS__>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
                        active_out, env->summary, env->log, env->ablog, env->p.flags, (const int32_t*)env->sizes, env->gscratch, \
                        env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
@@ -1798,7 +1819,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     // One-chunk layouts (one lane per agent and per task, lane 63 free for the depot) with all three observation buffers or
     // none: the register-resident kernel.  Same contract, same results (tests/test_gpu_rollout.py runs both).
     const bool all_obs = agents_out && tasks_out && mask_out, no_obs = !agents_out && !tasks_out && !mask_out;
-    if (env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
+    if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
 #define CALLF(CA, CT, RS, OBS)                                                                                        \
     hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS>), GRID(env),                                                  \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
@@ -1814,7 +1835,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
         return DCM_OK;
     }
     // BASELINE configs[3], 50A/200T exactly: the multi-chunk register-resident kernel (rollout_fast_mc.hpp)
-    if (!env->sizes && env->A == 50 && env->T == 200 && env->L.A == 50 && env->L.T == 200 && (all_obs || no_obs)) {
+    if (env->L.C == M && !env->sizes && env->A == 50 && env->T == 200 && env->L.A == 50 && env->L.T == 200 && (all_obs || no_obs)) {
 #define CALLM(OBS)                                                                                                    \
     hipLaunchKernelGGL((k_rollout_fast_mc<50, 200, OBS>), GRID(env), (FastM<50, 200, OBS>::LDS_BYTES), (hipStream_t)stream, \
                        DIMS(env), env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
@@ -1825,8 +1846,8 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
         return DCM_OK;
     }
 #endif
-#define CALL(CA, CT, RS)                                                                                              \
-    hipLaunchKernelGGL((k_rollout_random<CA, CT, RS>), GRID(env),                                                     \
+#define CALL(CA, CT, RS, ...)                                                                                         \
+    hipLaunchKernelGGL((k_rollout_random<CA, CT, RS, ##__VA_ARGS__>), GRID(env),                                                     \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS, ((CT) > WAVE) && !(RS)>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
@@ -1847,7 +1868,7 @@ int dcm_summary(dcm_env* env, double* out, void* stream) {
 int dcm_env_status(dcm_env* env, uint32_t* flags_out, int64_t* decisions_out, double* now_out, void* stream) {
     CHECK_ENV(env);
     const int B = env->p.n_envs;
-    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
+    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T, env->L.C,
                        env->state, B, flags_out, decisions_out, now_out, (int32_t*)nullptr);   // (layout dims: only the record pitch matters)
     LAUNCH_OK();
     return DCM_OK;
@@ -1857,7 +1878,7 @@ int dcm_env_episodes(dcm_env* env, int32_t* episodes_out, void* stream) {
     CHECK_ENV(env);
     if (!episodes_out) return fail(DCM_ERR_INVALID, "dcm_env_episodes: null episodes_out");
     const int B = env->p.n_envs;
-    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T,
+    hipLaunchKernelGGL(k_env_status, dim3((B + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, env->L.A, env->L.T, env->L.C,
                        env->state, B, (uint32_t*)nullptr, (int64_t*)nullptr, (double*)nullptr, episodes_out);
     LAUNCH_OK();
     return DCM_OK;
@@ -1866,9 +1887,11 @@ int dcm_env_episodes(dcm_env* env, int32_t* episodes_out, void* stream) {
 int dcm_get_tasks(dcm_env* env, uint8_t* finished, uint8_t* feasible, double* time_start, double* time_finish,
                   double* sum_wait, int32_t* status, int32_t* n_members, int32_t* n_abandoned, void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_tasks, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,
-                       env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned,
-                       env->ablog, (const int32_t*)env->sizes, env->gscratch);
+#define GETT(MCV) hipLaunchKernelGGL(k_get_tasks<MCV>, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp, \
+                       env->state, finished, feasible, time_start, time_finish, sum_wait, status, n_members, n_abandoned, \
+                       env->ablog, (const int32_t*)env->sizes, env->gscratch)
+    if (env->L.C > M) { GETT(MW); } else { GETT(M); }
+#undef GETT
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1877,9 +1900,11 @@ int dcm_get_agents(dcm_env* env, double* sum_wait, double* travel_dist, double* 
                    double* y, uint8_t* returned, uint8_t* assigned, int32_t* current, int32_t* pending_group,
                    void* stream) {
     CHECK_ENV(env);
-    hipLaunchKernelGGL(k_get_agents, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp,
-                       env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current,
-                       pending_group, env->ablog, (const int32_t*)env->sizes, env->gscratch);
+#define GETA(MCV) hipLaunchKernelGGL(k_get_agents<MCV>, GRID(env), env->L.lds_rec(), (hipStream_t)stream, DIMS(env), env->kp, \
+                       env->state, sum_wait, travel_dist, next_decision, arrival, x, y, returned, assigned, current, \
+                       pending_group, env->ablog, (const int32_t*)env->sizes, env->gscratch)
+    if (env->L.C > M) { GETA(MW); } else { GETA(M); }
+#undef GETA
     LAUNCH_OK();
     return DCM_OK;
 }
@@ -1888,7 +1913,7 @@ int dcm_get_members(dcm_env* env, int16_t* ids_out, void* stream) {
     CHECK_ENV(env);
     if (!ids_out) return fail(DCM_ERR_INVALID, "dcm_get_members: null ids_out");
     const int64_t n = (int64_t)env->p.n_envs * env->T;
-    hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->T, env->L.A, env->L.T,
+    hipLaunchKernelGGL(k_get_members, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, env->T, env->L.A, env->L.T, env->L.C,
                        env->state, env->p.n_envs, ids_out, (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;
@@ -1897,7 +1922,7 @@ int dcm_get_members(dcm_env* env, int16_t* ids_out, void* stream) {
 int dcm_get_abandoned(dcm_env* env, uint16_t* counts_out, void* stream) {
     CHECK_ENV(env);
     if (!counts_out) return fail(DCM_ERR_INVALID, "dcm_get_abandoned: null counts_out");
-    hipLaunchKernelGGL(k_get_abandoned, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->state, env->ablog, counts_out,
+    hipLaunchKernelGGL(k_get_abandoned, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->L.C, env->state, env->ablog, counts_out,
                        (const int32_t*)env->sizes);
     LAUNCH_OK();
     return DCM_OK;

@@ -765,6 +765,7 @@ int dcm_load_routes(dcm_env* env, const int32_t* routes, const int32_t* route_le
     CHECK_ENV(env);
     if (!routes || !route_len || route_cap < 1) return fail(DCM_ERR_INVALID, "dcm_load_routes: bad argument");
     if (member_cap < 1 || member_cap > MR_MAX) return fail(DCM_ERR_INVALID, "dcm_load_routes: member_cap must be in 1..32");
+    if (env->L.C != DCM_MAX_MEMBERS) return fail(DCM_ERR_STATE, "dcm_load_routes: not on a DCM_PARAM_WIDE_MEMBERS handle (route replay has its own member_cap)");
     if (replay_lds_bytes(env->A, env->T, member_cap) > 160 * 1024)
         return fail(DCM_ERR_INVALID, "dcm_load_routes: replay state does not fit the 160 KiB LDS; lower member_cap");
     const size_t nr = (size_t)env->p.n_envs * env->A * route_cap, nl = (size_t)env->p.n_envs * env->A;   // (CHECK_ENV: the handle's device is current)

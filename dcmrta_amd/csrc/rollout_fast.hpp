@@ -292,7 +292,7 @@ struct Fast {
             ids = rl(r.ids, tl);
             n = (kinfo >> 16) & 0xFF;
             slot = n + mypos;
-            if constexpr (TRK) dirty |= SimT::DIRTY_IDS | ((rl(r.lm, tl) & mm) ? 0x3Eu : ((((1u << nm) - 1u) << (n + 1)) & 0x3Eu));   // ids + the arrival rows written
+            if constexpr (TRK) dirty |= SimT::DIRTY_IDS | ((rl(r.lm, tl) & mm) ? SimT::DIRTY_ROWS : ((((1u << nm) - 1u) << (n + 1)) & SimT::DIRTY_ROWS));   // ids + the arrival rows written
             if (rl(r.lm, tl) & mm) {
                 // rare (Q4): walk the members in order as the reference does; every member's lane learns its own slot
                 for (int j = 0; j < nm; j++) {

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_step_fast(int A, int T, int PA, int
         const uint32_t Tn = (uint32_t)S.PT();
         put(0, L.tb());                                                               // header + agent arrays
         if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                            // time_start, time_finish
-        if ((dm & 0x3Eu) == 0x3Eu) put(L.marr(), L.mids());
+        if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
         else {
 #pragma unroll
             for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));

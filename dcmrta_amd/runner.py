@@ -135,8 +135,12 @@ class BatchedRunner:
         key = (A, T, bool(individual_selection), int(n_envs or self.B), strict)
         slot = self._cache.get(key)
         if slot is None:
-            slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection,
-                                           strict_mask=strict), graphs={})
+            # (under the capture lock: dcm_create allocates and may set kernel attributes -- not while another actor thread of
+            #  this process is in the middle of a stream capture)
+            from .graph_rollout import CAPTURE_LOCK
+            with CAPTURE_LOCK:
+                slot = dict(env=BatchedTaskEnv(key[3], A, T, device=str(self.device), individual_selection=individual_selection,
+                                               strict_mask=strict), graphs={})
             self._cache[key] = slot
             while len(self._cache) > self._cache_shapes:
                 _, old = self._cache.popitem(last=False)

@@ -37,8 +37,8 @@ class TaskEnv:
                  seed=None, plot_figure=False, device="cuda:0", choice_seed=0, individual_selection=False):
         if traits_dim != 1:
             raise NotImplementedError("traits_dim != 1 does not work in the reference either (SURVEY.md §5)")
-        if max_coalition_size > _lib.MAX_MEMBERS:
-            raise ValueError(f"max_coalition_size <= {_lib.MAX_MEMBERS}")
+        if max_coalition_size > _lib.MAX_MEMBERS_WIDE:
+            raise ValueError(f"max_coalition_size <= {_lib.MAX_MEMBERS_WIDE}")
         from .instances import generate_instance_ranges
         A, inst = generate_instance_ranges(agents_range, tasks_range, seed, max_coalition_size, max_duration)   # :58-71
         depot, task_xy, req, dur = inst["depot"], inst["task_xy"], inst["req"], inst["dur"]
@@ -64,7 +64,8 @@ class TaskEnv:
         self.dt = 0.1
         self._inst = (depot.copy(), task_xy.copy(), req.copy(), dur.copy())
         self._env = BatchedTaskEnv(1, A, self.tasks_num, device=device, max_waiting_time=self.max_waiting_time,
-                                   individual_selection=individual_selection)
+                                   individual_selection=individual_selection,
+                                   member_cap=_lib.MAX_MEMBERS_WIDE if int(np.max(req)) > _lib.MAX_MEMBERS else _lib.MAX_MEMBERS)
         self._env.load_instances(depot[None], task_xy[None], req[None], dur[None])
         self._env.enable_route_log(cap=self._ROUTE_CAP)         # agent['route'] / agent['arrival_time'] (:95-96,314,318)
         self._seed = np.array([choice_seed], dtype=np.uint64)

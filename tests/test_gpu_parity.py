@@ -18,7 +18,7 @@ def _env(B, A, T, dev, **kw):
 def test_native_library_loaded(gpu_device):
     from dcmrta_amd import _lib
     lib = _lib.load()
-    assert lib.dcm_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.dcm_abi_version() == _lib.ABI_VERSION == 5
     with open("/proc/self/maps") as f:
         assert "libdcmrta_hip.so" in f.read()
 
