@@ -139,22 +139,27 @@ struct Fast {
                     q1 |= e ? (1u << j) : 0u;
                     prev = e;
                 }
-                const uint32_t drop = le0 ? spread : q1;
-                const uint64_t ids = r.ids;
-                uint64_t nids = 0ull;
-                int k = 0;
+                const uint32_t drop = le0 ? spread : q1;                         // only listed slots can be set: unused ones hold NaN
+                const uint32_t keep = ((1u << n) - 1u) & ~drop;
+                // Compact the survivors in order, without a branch: vacate all slots, then every surviving member moves down to
+                // its rank among the survivors (a target never lies above its source, so earlier writes are never clobbered).
+                // At least one listed member leaves, so at most four survive: their ids fit the low word.
+                const uint32_t idl = (uint32_t)r.ids, idh = (uint32_t)(r.ids >> 32);
+                uint32_t nids = 0;
+#pragma unroll
+                for (int j = 0; j < M; j++) S.marr()[j * CT + lt] = __builtin_nan("");
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    const uint64_t id = (ids >> (8 * j)) & 0xFF;
-                    const bool listed = j < n, leaves = listed && ((drop >> j) & 1u);
-                    gone |= leaves ? (1ull << id) : 0ull;
-                    if (listed && !leaves) { nids |= id << (8 * k); S.marr()[k * CT + lt] = av[j]; k++; }
+                    const bool kp = (keep >> j) & 1u, lv = (drop >> j) & 1u;
+                    const int kj = __popc(keep & ((1u << j) - 1u));
+                    const uint32_t id = (j < 4 ? (idl >> (8 * j)) : idh) & 0xFFu;
+                    nids |= kp ? (id << (8 * kj)) : 0u;
+                    gone |= lv ? (1ull << id) : 0ull;
+                    S.marr()[(kp ? kj : j) * CT + lt] = kp ? av[j] : __builtin_nan("");
                 }
-#pragma unroll
-                for (int j = 0; j < M; j++) if (j >= k && j < n) S.marr()[j * CT + lt] = __builtin_nan("");   // vacated slots
-                r.ids = nids; r.lm &= ~gone;
-                r.nab += (uint32_t)(n - k);                                      // abandoned_agent.append :265/:271
-                nn = k;
+                r.ids = (uint64_t)nids; r.lm &= ~gone;
+                r.nab += (uint32_t)__popc(drop);                                 // abandoned_agent.append :265/:271
+                nn = __popc(keep);
             }
             if constexpr (TRK) dirty |= SimT::DIRTY_ALL & ~SimT::DIRTY_TIMES;   // slots compacted: every arrival row, ids, counts
             uint64_t todo = dmask;
