@@ -60,13 +60,14 @@ from dcmrta_amd.choice import env_seeds  # noqa: E402
 from dcmrta_amd.dist import DistContext, shard_range  # noqa: E402
 from dcmrta_amd.instances import generate_batch, synthetic_route_arrays  # noqa: E402
 from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step, issue_roofline, load_counters,  # noqa: E402
-                                 staleness)
+                                 rollout_kernel_name, staleness, step_kernel_name)
 
 REFERENCE_VISIBILITY = (20, 20, 10, 100)      # env/task_env.py:567, :221
 CONFIGS = {
     # name: envs, agents, tasks, episodes per pass, scaling, label, kernel
-    "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]", kernel="k_rollout_random"),
-    "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]", kernel="k_rollout_random"),
+    # (kernel: "rollout" = dcm_rollout_random -- which kernel that is for the shape: roofline.rollout_kernel_name)
+    "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]", kernel="rollout"),
+    "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]", kernel="rollout"),
     # 32 768 envs in total: the 8-GPU shard is 4096 envs = 4 waves per SIMD (at 8192 in total it was one wave per SIMD: pure latency)
     "5": dict(envs=32768, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
 }
@@ -181,7 +182,7 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
     ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
     Wb = algorithmic_bytes_per_step(A, T)
     c = load_counters(f"k_step:{B}x{A}A{T}T")
-    out = {"kernel": "k_step", "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
+    out = {"kernel": step_kernel_name(A, T), "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
            "achieved": B * Wb / ms / 1e6, "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
            "frac": B * Wb / ms / 1e6 / (HBM_PEAK_BYTES_PER_S / 1e9), "algorithmic_bytes_per_launch": B * Wb,
            "traffic": c.get("hbm_bytes_per_launch") if c else None,
@@ -247,6 +248,8 @@ def main():
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     A, T, EP = cfg["agents"], cfg["tasks"], cfg["episodes"]
+    if cfg["kernel"] == "rollout":
+        cfg["kernel"] = rollout_kernel_name(A, T)
     replay = cfg["kernel"] == "k_replay"
     static_replay = args.visibility == "static"
     visibility = (REFERENCE_VISIBILITY if (static_replay or not args.visibility) else tuple(int(x) for x in args.visibility.split(",")))

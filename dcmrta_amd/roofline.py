@@ -103,6 +103,21 @@ def issue_roofline(c, units_per_step, step_s, unit="decision"):
     return out
 
 
+def rollout_kernel_name(A, T):
+    """Which persistent rollout kernel dcm_rollout_random launches for a uniform batch of this shape (all three observation
+    buffers given): the register-resident kernels for the one-chunk layouts and for 50A/200T, the general one otherwise."""
+    if A <= 64 and T <= 63:
+        return "k_rollout_fast"
+    if (A, T) == (50, 200):
+        return "k_rollout_fast_mc"
+    return "k_rollout_random"
+
+
+def step_kernel_name(A, T):
+    """The lockstep kernel dcm_step launches for the plain call shape (no injected choices, no route log, all outputs)."""
+    return "k_step_fast" if (A <= 64 and T <= 63) else "k_step"
+
+
 def staleness(c, build_id):
     """True when the counter set was measured on another build of the kernels than the loaded library (dcm_build_id)."""
     return c.get("build_id") != build_id

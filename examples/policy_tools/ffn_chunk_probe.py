@@ -6,7 +6,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 dev = "cuda:0"
 rows, D, H = 4096 * 51, 128, 512
 dt = {"fp32": torch.float32, "fp16": torch.float16}[sys.argv[1] if len(sys.argv) > 1 else "fp32"]

@@ -8,7 +8,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dcmrta_amd.runner import BatchedRunner  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

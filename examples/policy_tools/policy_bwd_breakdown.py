@@ -6,7 +6,7 @@ import sys
 import torch
 from torch.profiler import ProfilerActivity, profile
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dcmrta_amd.policy import AttentionNet  # noqa: E402
 
 N, A, T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 20, 50

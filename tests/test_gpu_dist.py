@@ -44,7 +44,7 @@ def test_single_gpu_bench_contract_line(gpu_device):
     assert "workload" in j["config"] and "model" not in j["config"] and j["config"]["envs_per_gpu"] == 4096
     r = j["roofline"]
     # the persistent kernel is issue-bound: frac = VALU-busy SIMD-cycles / available SIMD-cycles, a utilisation (<= 1)
-    assert r["bound"] == "valu_issue" and r["kernel"] == "k_rollout_random" and r["peak"] == 1024 * 2.4
+    assert r["bound"] == "valu_issue" and r["kernel"] == "k_rollout_fast" and r["peak"] == 1024 * 2.4
     assert r["frac"] is not None and 0.05 < r["frac"] <= r["frac_hi"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.0 < r["salu_issue_frac"] <= 1.0 and r["pricing"]["calibration"].startswith("profiles/")
     assert 0.0 < r["lane_util"] <= 1.0 and r["counters_source"].startswith("profiles/")

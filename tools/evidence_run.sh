@@ -1,0 +1,22 @@
+#!/bin/bash
+# The round's evidence run (on the GPU box through gpurun): every rocprofv3 profile behind profiles/ + the contract lines.
+#   gpurun --timeout 3000 -- bash tools/evidence_run.sh r04      then, in the build container:  bash tools/collect_all.sh r04
+R=${1:-r04}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+bash tools/profile.sh ${R}_s4 --streams 4
+bash tools/profile.sh ${R}_s1 --streams 1
+bash tools/profile.sh ${R}_15A35T --agents 15 --tasks 35 --streams 1
+bash tools/profile.sh ${R}_c4 --config 4 --envs 8192 --streams 1
+bash tools/profile.sh ${R}_c5 --config 5
+bash tools/profile.sh ${R}_c5gen --config 5 --visibility 100,100,10,500
+bash tools/profile.sh ${R}_c5static --config 5 --visibility static
+bash tools/profile_lockstep.sh 4096 20 50 80
+bash tools/profile_lockstep.sh 65536 20 50 40
+bash tools/profile_lockstep.sh 16384 50 200 40
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
+python bench.py --config 4 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config4.json 2>> gpurun_out/${R}_bench.err
+python bench.py --config 5 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config5.json 2>> gpurun_out/${R}_bench.err
+python bench.py --config 5 --steps 10 --warmup 2 --visibility 100,100,10,500 > gpurun_out/${R}_bench_config5_generalised.json 2>> gpurun_out/${R}_bench.err
+python bench.py --config 5 --steps 10 --warmup 2 --visibility static > gpurun_out/${R}_bench_config5_static.json 2>> gpurun_out/${R}_bench.err
+tail -c 300 gpurun_out/${R}_bench.json
