@@ -37,9 +37,9 @@ def _pad_rows(x):
 def _layer_norm(x, ln):
     """nn.LayerNorm over the last dim, evaluated as a one-group GroupNorm of the [rows, D] matrix: the same arithmetic
     (per-row moments over D, per-channel affine), but at D = 128 and ~2e5 rows torch's layer-norm kernel takes 213 us per
-    call on MI355X and its group-norm kernels 110 us (tools/policy_bench.py).  Only without autograd (rollouts): the BACKWARD of
+    call on MI355X and its group-norm kernels 110 us (examples/policy_tools/policy_bench.py).  Only without autograd (rollouts): the BACKWARD of
     that group-norm call reduces the affine parameters' gradients over the ~1e5 rows one "sample" at a time
-    (GammaBeta1dBackwardCUDAKernel2: 94 of the 162 ms of a forward + backward over 8192 decisions, tools/policy_bwd_breakdown.py),
+    (GammaBeta1dBackwardCUDAKernel2: 94 of the 162 ms of a forward + backward over 8192 decisions, examples/policy_tools/policy_bwd_breakdown.py),
     so a forward that is going to be differentiated uses the layer-norm kernels."""
     if torch.is_grad_enabled() and (x.requires_grad or ln.weight.requires_grad):
         return F.layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
@@ -101,7 +101,7 @@ class GatedFFN(nn.Module):
         if x2.element_size() >= 4 and x2.shape[0] > 2 * n and not (torch.is_grad_enabled() and (x2.requires_grad or self.W2.weight.requires_grad)):
             # Rollout batch sizes (2e5 token rows): in row chunks, so that the [rows, 1024] product of the first GEMM is still in
             # the 256 MB MALL when F.glu and the second GEMM read it back instead of making two round trips through HBM
-            # (1.15 -> 1.01 ms per call in fp32 at 4096 x 51 rows, tools/ffn_chunk_probe.py; +1.5 ... 3 % on every fp32 row of
+            # (1.15 -> 1.01 ms per call in fp32 at 4096 x 51 rows, examples/policy_tools/ffn_chunk_probe.py; +1.5 ... 3 % on every fp32 row of
             # bench_configs.py --config 3).  fp32 only: with TunableOp-selected GEMMs the 2-byte shadows were 3 % FASTER in one
             # pass.  Same arithmetic per row; hipBLASLt may pick another tile for the smaller M (differences of the last bit).
             y = torch.empty_like(x2)

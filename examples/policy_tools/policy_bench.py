@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Forward time of the stand-in attention policy at rollout batch sizes (developer tool, GPU box).
-    python tools/policy_bench.py [B A T]"""
+    python examples/policy_tools/policy_bench.py [B A T]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-time breakdown of one forward of the stand-in attention policy at rollout batch size (developer tool, GPU box).
-    python tools/policy_breakdown.py [fp32|fp16|bf16] [B]"""
+    python examples/policy_tools/policy_breakdown.py [fp32|fp16|bf16] [B]"""
 import os
 import sys
 
