@@ -220,13 +220,14 @@ __device__ __forceinline__ double wave_nanmax(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
-// position of the idx-th (0-based) set bit of a wave-uniform mask; all 64 lanes must call
+// position of the idx-th (0-based) set bit of a wave-uniform mask, 0 <= idx < popcount(m); all 64 lanes must call.
+// v_mbcnt_lo/hi gives every lane the number of set bits below it; the lanes up to and including the wanted bit are exactly those
+// with at most idx of them, so one compare + one scalar popcount find it (an out-of-range idx gives -1 / 63: callers that probe
+// several mask words discard those).
 __device__ __forceinline__ int nth_set_bit(uint64_t m, int idx, int lane) {
-    const bool b = (m >> lane) & 1ull;
-    // v_mbcnt_lo/hi: number of set bits of m below this lane (two VALU ops, no lane-mask registers)
+    (void)lane;
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const uint64_t sel = __ballot(b && rank == idx);
-    return __ffsll((unsigned long long)sel) - 1;
+    return __popcll(__ballot(rank <= idx)) - 1;
 }
 
 // ---------------------------------------------------------------------------------- numpy add.reduce

@@ -925,6 +925,10 @@ struct Sim {
 
     // TaskEnv.step (env/task_env.py:326-342) + agent_step (:300-324) for leader + followers, then
     // task_update / agent_update (worker.py:74-76) and the move to the next decision point.
+    // DEV: the action comes from the device's own valid-action policy on a validated instance (persistent kernel): the error
+    // exits below cannot be taken and are compiled out -- each `return` in the middle of the step costs the structured control
+    // flow of the whole function scalar bookkeeping at every decision.
+    template <bool DEV = false>
     __device__ __forceinline__ void apply_and_advance(HdrRegs& h, const KP& P, int lane, int leader, const AMask& gm0,
                                                       int action, uint64_t k1, int nfol_in,
                                                       const int16_t* __restrict__ fol_in, double* __restrict__ row PH_ARGS,
@@ -938,8 +942,8 @@ struct Sim {
         // arrives makes its arrival list non-monotone, which is why the header keeps the episode's running maximum; 2 = from
         // the host with DCM_PARAM_STRICT_MASK: such an action freezes the env instead (DCM_FLAG_BAD_ACTION).
         const int A_ = A(), T_ = T();
-        if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
-        if (host_actions == 2 && action > 0) {
+        if constexpr (!DEV) { if (action < 0 || action > T_) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; } }
+        if (!DEV && host_actions == 2 && action > 0) {
             const uint32_t ik = uni(tinfo()[action - 1]);
             if ((ik & T_FEAS) || (int)(int8_t)((ik >> 8) & 0xFF) <= 0) { h.flags |= DCM_FLAG_BAD_ACTION | DCM_FLAG_DONE; return; }
         }
@@ -969,7 +973,9 @@ struct Sim {
                 const int vacancy = (int)(int8_t)((uni(tinfo()[k]) >> 8) & 0xFF);  // :327 task status (may be stale)
                 nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;  // :330-331
             }
-            if (nf > MC - 1 || nf > rlen || (nfol_in >= 0 && nf > DCM_FOLLOWER_COLS)) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+            if constexpr (!DEV) {
+                if (nf > MC - 1 || nf > rlen || (nfol_in >= 0 && nf > DCM_FOLLOWER_COLS)) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+            }
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                    // :331 choice without replacement
                 int f;
@@ -1043,7 +1049,7 @@ struct Sim {
                 int pos;
                 if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
                 else {
-                    if (n >= MC) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; }
+                    if constexpr (!DEV) { if (n >= MC) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; } }
                     pos = n++;
                     ids |= (uint64_t)(uint32_t)m << (8 * pos);                // bytes above n are always zero
                 }
@@ -1369,6 +1375,9 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
     float* tk = tasks_out ? tasks_out + (size_t)e * 5 * (BT + 1) : nullptr;
     uint8_t* mk = mask_out ? mask_out + (size_t)e * (BT + 1) : nullptr;
     if constexpr (RS || CA == 0) S.write_pad_obs(lane, BA, BT, ag, tk, mk);
+    // the usual call gives all three observation buffers: say so once, so that the per-decision null checks of observe() fold
+    // (wave-uniform branches otherwise, at every decision)
+    const bool all_obs = agents_out && tasks_out && mask_out;
     double* row = summary + (size_t)e * 8;
     // decisions left in this launch: a 32-bit countdown is the only loop-carried counter (steps = budget - left afterwards)
     constexpr int NO_BUDGET = 0x7FFFFFFF;
@@ -1397,11 +1406,12 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
             const int leader = S.pick_leader(h, lane, -1, k1, gm);
             if (leader < 0) break;
             PH_MARK(0);
-            S.observe(h, lane, leader, ag, tk, mk, xy);
+            if (all_obs) { __builtin_assume(ag != nullptr); __builtin_assume(tk != nullptr); __builtin_assume(mk != nullptr); S.observe(h, lane, leader, ag, tk, mk, xy); }
+            else S.observe(h, lane, leader, ag, tk, mk, xy);
             PH_MARK(1);
             const int action = S.pick_random_action(lane, k1);
             PH_MARK(2);
-            S.apply_and_advance(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, 0, true, false, &xy);
+            S.template apply_and_advance<true>(h, P, lane, leader, gm, action, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0, false, 0, true, false, &xy);
             gd += GAMMA;
             left--;
         }
