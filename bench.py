@@ -395,6 +395,16 @@ def main():
     if static_replay:
         vis_tag = ":static"
     c = load_counters(f"{cfg['kernel']}:{A}A{T}T{vis_tag}")      # per-step PMC averages measured by tools/profile.sh
+    counters_shape = None
+    if c is None and not replay:
+        # no profile committed for this very shape: price it with the instruction counts of the profiled shape that runs the same
+        # kernel (the per-decision counts of one kernel move by a few per cent with the shape: 406 vs 413 VALU at 20A/50T vs
+        # 15A/35T), and say so in the line
+        for key in {"k_rollout_fast": ("k_rollout_fast:20A50T",), "k_rollout_random": ("k_rollout_random:70A130T",)}.get(cfg["kernel"], ()):
+            c = load_counters(key)
+            if c is not None:
+                counters_shape = key.split(":", 1)[1]
+                break
     build = _lib.build_id()
     roof = {"kernel": cfg["kernel"], "avg_launch_ms": float(np.mean(launch_ms)), "launches_per_step": S,
             f"{unit}s_per_step": dec_per_step}
@@ -411,6 +421,8 @@ def main():
                              "unit": "GB/s", "frac": (traffic / step_s / HBM_PEAK_BYTES_PER_S) if traffic else None,
                              "note": "measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE) per pass / pass time"},
                      "counters_source": c.get("source"), "counters_build_id": c.get("build_id"), "build_id": build,
+                     # (set when the counters were profiled on another shape of the same kernel: an estimate, not this shape's own)
+                     "counters_shape": counters_shape,
                      # the counters describe the binary they were profiled on: a kernel edit without a re-profile shows here
                      "stale": staleness(c, build)})
     else:

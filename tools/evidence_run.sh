@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 bash tools/profile.sh ${R}_s4 --streams 4
 bash tools/profile.sh ${R}_s1 --streams 1
 bash tools/profile.sh ${R}_15A35T --agents 15 --tasks 35 --streams 1
+bash tools/profile.sh ${R}_70A130T --agents 70 --tasks 130 --streams 1
 bash tools/profile.sh ${R}_c4 --config 4 --envs 8192 --streams 1
 bash tools/profile.sh ${R}_c5 --config 5
 bash tools/profile.sh ${R}_c5gen --config 5 --visibility 100,100,10,500
