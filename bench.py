@@ -194,6 +194,29 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
     return out
 
 
+def other_config_shards(dev, visibility, passes=4):
+    """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 4096 envs x
+    100A/500T route replay with dynamic arrivals), timed inside the DEFAULT run so that whoever clocks `python bench.py` also
+    clocks them: one warm pass, then `passes` passes back to back, one stream, inputs resident in HBM.  The full lines of these
+    configs (roofline, cpu_baseline, sharding) are `bench.py --config 4` / `--config 5`."""
+    out = {}
+    for name, cfg, B in (("config4_shard", CONFIGS["4"], 8192), ("config5_shard", CONFIGS["5"], 4096)):
+        A, T = cfg["agents"], cfg["tasks"]
+        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"])
+        sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)
+        sb.run(1, True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        counts = [sb.run(1, True)[0] for _ in range(passes)]
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        n = int(torch.stack(counts).sum().item())
+        out[name] = {"workload": f"{B} envs x {A}A/{T}T, the per-GPU shard of {cfg['label']} on 8 GPUs", "kernel": c["kernel"],
+                     "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes}
+        sb.env.close()
+    return out
+
+
 class SubBatch:
     """One contiguous block of the rank's envs: its own handle and (for more than one sub-batch) its own HIP stream."""
 
@@ -242,6 +265,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="config 2, one GPU: do not time the per-GPU shards of configs 4 / 5 (other_configs) after the run")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("envs", "agents", "tasks", "episodes"):
@@ -464,6 +489,12 @@ def main():
         for sb in subs:
             sb.env.close()
         out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)
+    # (only in the full default run: the profiling / A-B tools pass --no-lockstep-probe --no-cpu-baseline and must see one kernel)
+    if ctx.world == 1 and args.config == "2" and not (args.no_other_configs or args.no_lockstep_probe or args.no_cpu_baseline) and \
+            all(getattr(args, k) is None for k in ("envs", "agents", "tasks")):
+        for sb in subs:
+            sb.env.close()
+        out["other_configs"] = other_config_shards(dev, REFERENCE_VISIBILITY)
     if ctx.world == 1 and not args.no_cpu_baseline:
         sb = subs[0]
         inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}

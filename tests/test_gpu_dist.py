@@ -149,3 +149,20 @@ def test_plain_command_propagates_rank_failure(gpu_device):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--agents", "4000"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_default_line_times_the_other_baseline_configs(gpu_device):
+    """The full default run (what the driver clocks) also times the per-GPU shards of BASELINE configs[3] and configs[4] and the
+    HBM-bound lockstep kernel, after the timed region."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    oc = j["other_configs"]
+    assert oc["config4_shard"]["kernel"] == "k_rollout_fast_mc" and oc["config4_shard"]["value"] > 1e8
+    assert 8192 * 200 < oc["config4_shard"]["steps_per_pass"] < 8192 * 500           # ~320 decisions per 50A/200T episode
+    assert oc["config5_shard"]["kernel"] == "k_replay" and oc["config5_shard"]["value"] > 1e8
+    lk = j["lockstep_kernel"]
+    assert lk["kernel"] == "k_step_fast" and 0.2 < lk["frac"] < 1.2 and (lk["traffic_frac"] is None or lk["traffic_frac"] < lk["frac"])
+    assert j["cpu_baseline"]["value"] > 0 and j["value"] > 1e6
