@@ -10,8 +10,8 @@ One bench "step" = one pass of the hot path over one batch.
 --config 4 = BASELINE.json configs[3]: 65 536 envs of 50A/200T in total, sharded over the N ranks by contiguous blocks
     (strong scaling), one episode per env per pass.
 --config 5 = BASELINE.json configs[4]: route replay (execute_by_route) of 100A/500T instances with dynamic task arrivals,
-    32 768 envs in total sharded over the N ranks (strong scaling; BASELINE does not fix the count: chosen so that the 8-GPU
-    shard still holds four waves per SIMD); a step of this config = one agent_step call of the
+    65 536 envs in total sharded over the N ranks (strong scaling; BASELINE does not fix the count: chosen, like config 4's, so
+    that the 8-GPU shard is still several rounds of resident waves); a step of this config = one agent_step call of the
     replay.  Preset routes are synthetic (the reference ships routes for 20A/50T only).  --visibility initial,batch,period,cap
     selects another dynamic-arrival schedule than the reference's hard-coded 20,20,10,100 (under which tasks 101..500 never
     appear): reported as a separate workload, never as the config-5 number.
@@ -68,8 +68,10 @@ CONFIGS = {
     # (kernel: "rollout" = dcm_rollout_random -- which kernel that is for the shape: roofline.rollout_kernel_name)
     "2": dict(envs=4096, agents=20, tasks=50, episodes=3, scaling="weak", label="BASELINE configs[1]", kernel="rollout"),
     "4": dict(envs=65536, agents=50, tasks=200, episodes=1, scaling="strong", label="BASELINE configs[3]", kernel="rollout"),
-    # 32 768 envs in total: the 8-GPU shard is 4096 envs = 4 waves per SIMD (at 8192 in total it was one wave per SIMD: pure latency)
-    "5": dict(envs=32768, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
+    # 65 536 envs in total (BASELINE does not fix the count; the same as config 4): the 8-GPU shard is 8192 envs = 2.3 rounds of the 14
+    # waves a CU holds.  One round is latency-bound (2.99 ms for 3584 envs, 3.14 for 4096, 4.7 for 7168): at 8192 envs in total the
+    # shard was one wave per SIMD and 8 GPUs would have been 3.5x one; at 32 768, 5.7x; here the measured per-shard rate predicts 6.7x
+    "5": dict(envs=65536, agents=100, tasks=500, episodes=1, scaling="strong", label="BASELINE configs[4]", kernel="k_replay"),
 }
 AUTO_STREAM_CANDIDATES = (4, 2, 1)   # --streams 0: pick the fastest of these in an untimed calibration before the warm-up
 
@@ -195,12 +197,12 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
 
 
 def other_config_shards(dev, visibility, passes=4):
-    """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 4096 envs x
+    """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 8192 envs x
     100A/500T route replay with dynamic arrivals), timed inside the DEFAULT run so that whoever clocks `python bench.py` also
     clocks them: one warm pass, then `passes` passes back to back, one stream, inputs resident in HBM.  The full lines of these
     configs (roofline, cpu_baseline, sharding) are `bench.py --config 4` / `--config 5`."""
     out = {}
-    for name, cfg, B in (("config4_shard", CONFIGS["4"], 8192), ("config5_shard", CONFIGS["5"], 4096)):
+    for name, cfg, B in (("config4_shard", CONFIGS["4"], 8192), ("config5_shard", CONFIGS["5"], 8192)):
         A, T = cfg["agents"], cfg["tasks"]
         c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"])
         sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)

@@ -1653,6 +1653,7 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
     const int dev_slot = params->device & 63;
     int lds = (int)(h->L.lds_rec() + align16(4u * (uint32_t)h->L.T));   // (+ the wake-up times of the multi-chunk layouts)
     if (h->L.lds_bytes() <= 10240) lds = (int)h->L.lds_bytes();           // persistent kernel of the small layouts: scratch in LDS
+    if (lds + 512 <= 160 * 1024) lds += 512;                               // the register-resident kernels' dummy slots (small layouts)
     // (only when the limit really grows: the attribute calls of one host thread must not keep landing in another thread's
     //  stream capture -- actors create handles for new batch shapes while others capture)
     const bool grow = lds > lds_limit[dev_slot];
@@ -1798,7 +1799,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
         mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
 #define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp, \
+    hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), env->kp, \
                        env->state, actions, agents_out, tasks_out, mask_out, leader_out, active_out, env->summary, env->ablog,  \
                        env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
         const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
@@ -1832,7 +1833,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
 #define CALLF(CA, CT, RS, OBS)                                                                                        \
     hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS>), GRID(env),                                                  \
-                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), \
+                       (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
 #define CALL(CA, CT, RS) do { if (all_obs) { CALLF(CA, CT, RS, true); } else { CALLF(CA, CT, RS, false); } } while (0)

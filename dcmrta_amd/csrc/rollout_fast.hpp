@@ -13,9 +13,11 @@
 //   * wave-uniform reads of a chosen lane's state (the leader's position, the chosen task's status word / ids / position) are
 //     v_readlane -- no LDS round trip; per-lane reads of own state cost nothing;
 //   * LDS carries only what another lane must read by INDEX: the member arrival slots f64[M][T] (written by the joining agents'
-//     lanes, read by the task's lane), the status words and the two time arrays (written through by the task lanes, gathered by
-//     the agents' lanes in agent_update), and -- for the member-removal path, which scatters from a task's lane to its members --
-//     route[-1] and the flag words of the agents (written through by agent_step);
+//     lanes, read by the task's lane), and the status words and the two time arrays (written through by the task lanes, gathered
+//     by the agents' lanes in agent_update);
+//   * member removal needs no scatter from a task's lane to its members: the task's lane compacts its own slots and publishes a
+//     `gone` agent bitmask, and a wave-uniform pass over the dropping tasks lets each agent's lane take its own abandonment
+//     (v_readlane of the mask) -- the agents' counters and flags never leave their registers;
 //   * the lane code is select-based (no per-lane branches except the member-removal compaction), error returns do not exist on
 //     this path (the device policy only takes valid actions on a validated instance), the observation pointers are a template
 //     parameter, and every loop / branch condition is wave-uniform in SGPRs.
@@ -24,6 +26,7 @@
 //
 // Reference restated: worker.py:45-87 (loop), env/task_env.py:161-342 (the functions named at each block below).
 #pragma once
+#include <type_traits>
 
 // TRK (lockstep kernel): the fast path records which task sections of the record it has changed (Sim::DIRTY_* bits), so that
 // the write-back can skip the others
@@ -36,6 +39,7 @@ struct Fast {
     static constexpr Lay L{CA, CT};
 
     SimT S;
+    double* dummy;                                     // 64 doubles of LDS nobody reads (the removal path's discarded writes)
     mutable uint32_t dirty = 0;                        // TRK only
     uint64_t am, tm;                                   // lanes that own an agent / a task (wave-uniform masks)
     // per-lane constants
@@ -129,34 +133,48 @@ struct Fast {
             // task's lane compacts its own slots; the agents' lanes then take their abandonment from the task's `gone` mask --
             // no scatter through LDS: an agent's counters live in its own lane.
             uint64_t gone = 0ull;
-            if (any_drop) {
-                uint32_t spread = 0, q1 = 0;
+            // (which of the two removal rules is in play is wave-uniform almost always -- the spread rule fires ~3 times per
+            //  episode -- so the per-slot tests of the other one are skipped by a scalar branch)
+            const bool any_spread = __ballot(any_drop && le0) != 0ull, any_wait = __ballot(any_drop && !le0) != 0ull;
+            uint32_t spread = 0, q1 = 0;
+            if (any_spread) {
+#pragma unroll
+                for (int j = 0; j < M; j++) spread |= (av[j] <= thr) ? (1u << j) : 0u;       // :262-265
+            }
+            if (any_wait) {
                 bool prev = false;
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    spread |= (av[j] <= thr) ? (1u << j) : 0u;                   // :262-265
-                    const bool e = !prev && (now - av[j] >= mwt);                // :269, skipping the element after a removal
+                    const bool e = !prev && (now - av[j] >= mwt);                // :269, skipping the element after a removal (Q1)
                     q1 |= e ? (1u << j) : 0u;
                     prev = e;
                 }
+            }
+            if (any_drop) {
                 const uint32_t drop = le0 ? spread : q1;                         // only listed slots can be set: unused ones hold NaN
                 const uint32_t keep = ((1u << n) - 1u) & ~drop;
                 // Compact the survivors in order, without a branch: vacate all slots, then every surviving member moves down to
-                // its rank among the survivors (a target never lies above its source, so earlier writes are never clobbered).
-                // At least one listed member leaves, so at most four survive: their ids fit the low word.
+                // its rank among the survivors (a target never lies above its source, so earlier writes are never clobbered);
+                // the leavers' writes go to a per-lane dummy slot.  At least one listed member leaves, so at most four survive:
+                // their ids fit the low word.
                 const uint32_t idl = (uint32_t)r.ids, idh = (uint32_t)(r.ids >> 32);
                 uint32_t nids = 0;
+                using gone_t = typename std::conditional<(CA <= 32), uint32_t, uint64_t>::type;   // agent ids below 32: one word
+                gone_t g = 0;
+                double* const row0 = S.marr() + lt;
+                double* const dump = dummy + lane;
 #pragma unroll
-                for (int j = 0; j < M; j++) S.marr()[j * CT + lt] = __builtin_nan("");
+                for (int j = 0; j < M; j++) row0[j * CT] = __builtin_nan("");
 #pragma unroll
                 for (int j = 0; j < M; j++) {
                     const bool kp = (keep >> j) & 1u, lv = (drop >> j) & 1u;
                     const int kj = __popc(keep & ((1u << j) - 1u));
                     const uint32_t id = (j < 4 ? (idl >> (8 * j)) : idh) & 0xFFu;
                     nids |= kp ? (id << (8 * kj)) : 0u;
-                    gone |= lv ? (1ull << id) : 0ull;
-                    S.marr()[(kp ? kj : j) * CT + lt] = kp ? av[j] : __builtin_nan("");
+                    g |= lv ? ((gone_t)1 << id) : (gone_t)0;
+                    *(kp ? row0 + kj * CT : dump) = av[j];
                 }
+                gone = (uint64_t)g;
                 r.ids = (uint64_t)nids; r.lm &= ~gone;
                 r.nab += (uint32_t)__popc(drop);                                 // abandoned_agent.append :265/:271
                 nn = __popc(keep);
@@ -397,7 +415,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     S.set_retlog(retlog, retcap, e, lane);
     WSYNC();
     HdrRegs h = load_hdr(smem);
-    F f{S};
+    // (the launch asks for 512 bytes of LDS behind everything the general code uses: the dummy slots)
+    F f{S, (double*)(smem + (SimT::SCR_IN_LDS ? L.lds_bytes() : SimT::lds_image_bytes(L)))};
     f.init(lane);
     float* agrow = nullptr; float* tkrow = nullptr; uint8_t* mkp = nullptr;
     if constexpr (OBS) {

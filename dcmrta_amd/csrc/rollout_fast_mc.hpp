@@ -57,7 +57,7 @@ struct FastM {
     // by nobody on the fast path (the agents get it broadcast at that moment) -- sits in f64[T] of LDS behind the image; the
     // wake-up times use the image's own f32[T] array, which the arrival slots do not cover.
     __device__ __forceinline__ double* ts_x() const { return (double*)(S.base + SimT::lds_image_bytes(L)); }
-    static constexpr uint32_t LDS_BYTES = SimT::lds_image_bytes(Lay{CA, CT}) + 8u * CT;
+    static constexpr uint32_t LDS_BYTES = SimT::lds_image_bytes(Lay{CA, CT}) + 8u * CT + 512u;   // + the removal path's dummy slots
 
     __device__ __forceinline__ double* slots() const { return (double*)(S.base + SLOTS_OFF); }
     __device__ __forceinline__ static bool in_task(int c, int lane) { return c * 64 + lane < CT; }
@@ -160,25 +160,31 @@ struct FastM {
         const uint64_t dmask = __ballot(any_drop);
         if (dmask) {
             uint64_t gone = 0ull;
-            if (any_drop) {
-                uint32_t spread = 0, q1 = 0;
+            // (see Fast::task_update: the rule that is not in play is skipped by a scalar branch; leavers write to a dummy slot)
+            const bool any_spread = __ballot(any_drop && le0) != 0ull, any_wait = __ballot(any_drop && !le0) != 0ull;
+            uint32_t spread = 0, q1 = 0;
+            if (any_spread) {
+#pragma unroll
+                for (int j = 0; j < M; j++) spread |= (av[j] <= thr) ? (1u << j) : 0u;       // :262-265
+            }
+            if (any_wait) {
                 bool prev = false;
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    spread |= (av[j] <= thr) ? (1u << j) : 0u;                   // :262-265
                     const bool e = !prev && (now - av[j] >= mwt);                // :269, skipping the element after a removal (Q1)
                     q1 |= e ? (1u << j) : 0u;
                     prev = e;
                 }
+            }
+            if (any_drop) {
                 const uint32_t drop = le0 ? spread : q1;                         // only listed slots can be set: unused ones hold NaN
                 const uint32_t keep = ((1u << n) - 1u) & ~drop;
-                // Compact the survivors in order, without a branch: vacate all slots, then every surviving member moves down to
-                // its rank among the survivors (a target never lies above its source, so earlier writes are never clobbered).
-                // At least one listed member leaves, so at most four survive: their ids fit the low word.
                 const uint32_t idl = (uint32_t)r.ids[C], idh = (uint32_t)(r.ids[C] >> 32);
                 uint32_t nids = 0;
+                double* const row0 = slots() + t;
+                double* const dump = ts_x() + CT + lane;                         // 64 doubles behind the time_start array
 #pragma unroll
-                for (int j = 0; j < M; j++) slots()[j * CT + t] = __builtin_nan("");
+                for (int j = 0; j < M; j++) row0[j * CT] = __builtin_nan("");
 #pragma unroll
                 for (int j = 0; j < M; j++) {
                     const bool kp = (keep >> j) & 1u, lv = (drop >> j) & 1u;
@@ -186,7 +192,7 @@ struct FastM {
                     const uint32_t id = (j < 4 ? (idl >> (8 * j)) : idh) & 0xFFu;
                     nids |= kp ? (id << (8 * kj)) : 0u;
                     gone |= lv ? (1ull << id) : 0ull;
-                    slots()[(kp ? kj : j) * CT + t] = kp ? av[j] : __builtin_nan("");
+                    *(kp ? row0 + kj * CT : dump) = av[j];
                 }
                 r.ids[C] = (uint64_t)nids;
                 S.tnab()[t] += (uint32_t)__popc(drop);                           // abandoned_agent.append :265/:271 (section not covered)

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_step_fast(int A, int T, int PA, int
     if (lane == 0) *S.dirty() = 0;
     WSYNC();
     HdrRegs h = load_hdr(smem);
-    F f{S};
+    F f{S, (double*)(smem + SimT::lds_image_bytes(L))};      // (512 bytes of LDS behind the image: the removal path's dummy slots)
     f.init(lane);
     typename F::R r;
     bool regs = false;       // the registers hold the env: agent arrays / member ids / abandonment counts of the LDS image are stale
