@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dcmrta_env.h")
 ABI_VERSION = 5
 FOLLOWER_COLS = 4
 MAX_MEMBERS = 5
-MAX_MEMBERS_WIDE = 8     # DCM_PARAM_WIDE_MEMBERS handles
+MAX_MEMBERS_WIDE = 16    # DCM_PARAM_WIDE_MEMBERS handles
 PARAM_NO_GROUPING, PARAM_AUTO_RESET, PARAM_STRICT_MASK, PARAM_WIDE_MEMBERS = 1, 2, 4, 8
 MAX_AGENTS = 128
 MAX_TASKS = 1023

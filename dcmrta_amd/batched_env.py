@@ -60,7 +60,7 @@ class BatchedTaskEnv:
         # strict_mask: freeze an env whose host-supplied action is on a masked task (DCM_PARAM_STRICT_MASK) instead of
         # simulating it like the reference's TaskEnv.step does
         # member_cap: member slots per task -- 5 (COALITION_SIZE, parameters.py:17) or, for a mask-ignoring policy (worker.py:140) or
-        # max_coalition_size > 5 (env/task_env.py:71), 8 (DCM_PARAM_WIDE_MEMBERS: larger records, runtime-size kernels, no replay)
+        # max_coalition_size > 5 (env/task_env.py:71), 16 (DCM_PARAM_WIDE_MEMBERS: larger records, runtime-size kernels, no replay)
         if not 1 <= int(member_cap) <= _lib.MAX_MEMBERS_WIDE:
             raise DcmError(f"member_cap must be in 1..{_lib.MAX_MEMBERS_WIDE}")
         self.member_cap = _lib.MAX_MEMBERS if int(member_cap) <= _lib.MAX_MEMBERS else _lib.MAX_MEMBERS_WIDE

@@ -70,8 +70,9 @@ struct Lay {
     __host__ __device__ constexpr uint32_t ts() const { return tb(); }               // f64[T] time_start
     __host__ __device__ constexpr uint32_t tf() const { return tb() + 8 * T; }       // f64[T] time_finish
     __host__ __device__ constexpr uint32_t marr() const { return tb() + 16 * T; }    // f64[C][T] member arrivals
-    __host__ __device__ constexpr uint32_t mids() const { return marr() + 8 * C * T; }   // u64[T] ordered member ids (one byte each, C <= 8)
-    __host__ __device__ constexpr uint32_t tinfo() const { return mids() + 8 * T; }  // u32[T]
+    __host__ __device__ constexpr uint32_t idw() const { return (uint32_t)(C + 7) / 8; }   // 64-bit id words per task
+    __host__ __device__ constexpr uint32_t mids() const { return marr() + 8 * C * T; }   // u64[idw][T] ordered member ids, one byte each
+    __host__ __device__ constexpr uint32_t tinfo() const { return mids() + 8 * idw() * T; }  // u32[T]
     __host__ __device__ constexpr uint32_t tnab() const { return tinfo() + 4 * T; }  // u32[T] len(abandoned_agent)
     __host__ __device__ constexpr uint32_t mut_bytes() const { return align16(tnab() + 4 * T); }
     __host__ __device__ constexpr uint32_t tx() const { return mut_bytes(); }        // f64[T] task x (instance)
@@ -97,7 +98,37 @@ struct Lay {
 static_assert(Lay{20, 50}.rec_bytes() == 5824, "S(20,50) = 64 + 48A + 96T");
 static_assert(Lay{20, 50}.mids() == Lay{20, 50}.tb() + 56 * 50 && Lay{20, 50}.mut_bytes() == align16(Lay{20, 50}.tb() + 72 * 50), "5 member slots: the canonical record");
 constexpr int MW = DCM_MAX_MEMBERS_WIDE;
-static_assert(MW <= 8, "member ids are one byte each of a 64-bit word");
+static_assert(MW <= 16, "member ids: one byte each of up to two 64-bit words");
+
+// Ordered member ids of one task: byte j of the word array = members[j] (the order matters: quirk Q1).  One word for the 5 slots
+// of an ordinary handle (everything below folds to the single-word code), two for the 16 of a wide one.
+template <int IW>
+struct IdW {
+    uint64_t w[IW];
+    __host__ __device__ __forceinline__ uint32_t byte(int j) const {
+        uint64_t x = w[0] >> (8 * (j & 7));
+#pragma unroll
+        for (int i = 1; i < IW; i++) if ((j >> 3) == i) x = w[i] >> (8 * (j & 7));
+        return (uint32_t)x & 0xFFu;
+    }
+    __host__ __device__ __forceinline__ void put(int pos, uint32_t id) {      // byte `pos` must be zero (bytes above n always are)
+#pragma unroll
+        for (int i = 0; i < IW; i++) if ((pos >> 3) == i) w[i] |= (uint64_t)id << (8 * (pos & 7));
+    }
+    // position of `id` among the first n bytes, -1 if it is not listed (SWAR zero-byte search per word)
+    __host__ __device__ __forceinline__ int find(uint32_t id, int n) const {
+        int pos = -1;
+#pragma unroll
+        for (int i = IW - 1; i >= 0; i--) {
+            const int ni = n - 8 * i;                                             // bytes of this word that are listed
+            const uint64_t x = w[i] ^ (0x0101010101010101ull * (uint64_t)id);
+            uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;  // lowest set bit = first zero byte
+            z &= (ni >= 8) ? ~0ull : (ni <= 0 ? 0ull : ((1ull << (8 * ni)) - 1ull));
+            if (z) pos = 8 * i + ((__builtin_ffsll((long long)z) - 1) >> 3);
+        }
+        return pos;
+    }
+};
 
 struct KP {
     double mwt;       // max_waiting_time

@@ -85,6 +85,8 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 template <int CA, int CT, bool RS, bool MG = false, int MC = M>
 struct Sim {
     static_assert(MC == M || (MC == MW && CA == 0 && !MG), "wide member slots: runtime-size instantiation only");
+    static constexpr int IW = (MC + 7) / 8;               // 64-bit id words per task
+    using Ids = IdW<IW>;
     static constexpr int NAW = CA ? (CA + 63) / 64 : AW_MAX;  // agent chunks == words of an agent bitmask
     static constexpr int NTC = CT ? (CT + 63) / 64 : 0;       // task lane chunks (0 = runtime)
     static constexpr bool EXACT = (CA != 0) && !RS;
@@ -149,7 +151,14 @@ struct Sim {
     __device__ __forceinline__ double* ts() const { return (double*)(base + L().ts()); }
     __device__ __forceinline__ double* tf() const { return (double*)(base + L().tf()); }
     __device__ __forceinline__ double* marr() const { if constexpr (MG) return gm; else return (double*)(base + L().marr()); }
-    __device__ __forceinline__ uint64_t* mids() const { return (uint64_t*)(base + L().mids() - MSH); }
+    __device__ __forceinline__ uint64_t* mids() const { return (uint64_t*)(base + L().mids() - MSH); }   // u64[IW][PT], word-major
+    __device__ __forceinline__ Ids load_ids(int t) const { Ids x;
+#pragma unroll
+        for (int i = 0; i < IW; i++) x.w[i] = mids()[i * PT() + t];
+        return x; }
+    __device__ __forceinline__ void store_ids(int t, const Ids& x) const {
+#pragma unroll
+        for (int i = 0; i < IW; i++) mids()[i * PT() + t] = x.w[i]; }
     __device__ __forceinline__ uint32_t* tinfo() const { return (uint32_t*)(base + L().tinfo() - MSH); }
     __device__ __forceinline__ uint32_t* tnab() const { return (uint32_t*)(base + L().tnab() - MSH); }
     __device__ __forceinline__ double* tx() const { return (double*)(base + L().tx()); }
@@ -302,8 +311,8 @@ struct Sim {
     __device__ __forceinline__ int32_t* inc_state() const { return (int32_t*)(base + aux_off() + 8); }
     __device__ __forceinline__ float* wake() const { return (float*)(base + aux_off() + 48); }    // f32[PT], INC kernels only
     // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..MC member-arrival row j,
-    // bit 12 member ids, bit 13 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
-    static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_ROWS = ((1u << MC) - 1u) << 1, DIRTY_IDS = 1u << 12, DIRTY_NAB = 1u << 13,
+    // bit 20 member ids, bit 21 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
+    static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_ROWS = ((1u << MC) - 1u) << 1, DIRTY_IDS = 1u << 20, DIRTY_NAB = 1u << 21,
                               DIRTY_ALL = DIRTY_TIMES | DIRTY_ROWS | DIRTY_IDS | DIRTY_NAB;
     __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + aux_off() + 24); }
     __device__ __forceinline__ void task_update(const HdrRegs& h, const KP& P, int lane, int only = -1, bool track = false) const {
@@ -349,12 +358,12 @@ struct Sim {
                         prev = e;
                     }
                     const uint32_t drop = le0 ? spread : q1;
-                    const uint64_t ids = mids()[t];
-                    uint64_t nids = 0;
+                    const Ids ids = load_ids(t);
+                    Ids nids{};
                     int k = 0;
 #pragma unroll
                     for (int j = 0; j < MC; j++) if (j < n) {
-                        const uint32_t id = (uint32_t)((ids >> (8 * j)) & 0xFF);
+                        const uint32_t id = ids.byte(j);
                         if (drop & (1u << j)) {
                             // abandoned_agent.append(member) :265/:271; the agent stops being listed at `t`
                             const uint32_t nth = atomicAdd(&ainfo()[id], 1u << 16) >> 16;
@@ -362,13 +371,13 @@ struct Sim {
                             else { const uint32_t ci = (uint32_t)(id * T_ + t); atomicAdd((uint32_t*)abcnt() + (ci >> 1), 1u << (16 * (ci & 1))); }
                             if (cur()[id] == t) atomicAnd(&ainfo()[id], ~A_MEMBER);
                         } else {
-                            nids |= (uint64_t)id << (8 * k);
+                            nids.put(k, id);
                             marr()[k * PT_ + t] = av[j];
                             k++;
                         }
                     }
                     for (int j = k; j < n; j++) marr()[j * PT_ + t] = __builtin_nan("");  // vacated slots
-                    mids()[t] = nids;
+                    store_ids(t, nids);
                     tnab()[t] += (uint32_t)(n - k);
                     nn = k;
                     if (track) atomicOr(dirty(), DIRTY_ALL & ~DIRTY_TIMES);   // slots compacted: every arrival row, ids, counts
@@ -486,14 +495,25 @@ struct Sim {
             double s = 0., term[MC];
 #pragma unroll
             for (int j = 0; j < MC; j++) { term[j] = feas ? mx - av[j] : now - av[j]; s = (j < n) ? s + term[j] : s; }   // :351 / :354
-            if constexpr (MC >= 8) {   // np.sum of exactly eight terms is numpy's unrolled pairwise block, not a running sum
-                if (n == 8) s = ((term[0] + term[1]) + (term[2] + term[3])) + ((term[4] + term[5]) + (term[6] + term[7]));
+            if constexpr (MC >= 8) {   // np.sum of eight or more terms is numpy's unrolled pairwise block, not a running sum
+                if (n >= 8) {
+                    double r8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) r8[j] = term[j];
+                    if constexpr (MC >= 16) { if (n >= 16) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) r8[j] += term[8 + j]; } }
+                    s = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                    const int nb = n - (n % 8);
+#pragma unroll
+                    for (int j = 8; j < MC; j++) s = (j >= nb && j < n) ? s + term[j] : s;
+                }
             }
             tw()[t] = s + ab;                                                // :351-357
             tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
-            const uint64_t ids = mids()[t];
+            const Ids ids = load_ids(t);
             for (int j = 0; j < n; j++)                                      // transpose members -> per-agent task set
-                atomicOr(&amask()[(int)((ids >> (8 * j)) & 0xFF) * TW + (t >> 6)], 1ull << (t & 63));
+                atomicOr(&amask()[(int)ids.byte(j) * TW + (t >> 6)], 1ull << (t & 63));
         });
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt1 = __builtin_readcyclecounter();
@@ -522,7 +542,6 @@ struct Sim {
             }
             int p = 0;
             double s = 0.;
-            const uint64_t pat = 0x0101010101010101ull * (uint64_t)(uint32_t)a;
             // merge, in ascending task id, the tasks that list the agent (member term) with its abandonment entries
             for (int w = 0; w < TW; w++) {
                 uint64_t m = amask()[a * TW + w];
@@ -534,10 +553,7 @@ struct Sim {
                     m &= m - 1;
                     const uint32_t info = tinfo()[tm];
                     const int n = (info >> 16) & 0xFF;
-                    const uint64_t x = mids()[tm] ^ pat;
-                    uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-                    z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
-                    const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                    const int pos = load_ids(tm).find((uint32_t)a, n);
                     const double mine = marr()[pos * PT_ + tm];
                     const double wv = now - mine;
                     s += (info & T_FEAS) ? (tmx()[tm] - mine) : ((wv > 0.) ? wv : 0.);   // :360 / :362
@@ -553,10 +569,7 @@ struct Sim {
                     if ((amask()[a * TW + (t >> 6)] >> (t & 63)) & 1ull) {
                         const uint32_t info = tinfo()[t];
                         const int n = (info >> 16) & 0xFF;
-                        const uint64_t x = mids()[t] ^ pat;
-                        uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-                        z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
-                        const int pos = (__ffsll((unsigned long long)z) - 1) >> 3;
+                        const int pos = load_ids(t).find((uint32_t)a, n);
                         const double mine = marr()[pos * PT_ + t];
                         const double wv = now - mine;
                         s += (info & T_FEAS) ? (tmx()[t] - mine) : ((wv > 0.) ? wv : 0.);
@@ -798,7 +811,7 @@ struct Sim {
             const uint32_t req = tinfo()[t] & 0xFF;
             tinfo()[t] = req | (req << 8);       // status = requirements :131, members [], not feasible/finished
             tnab()[t] = 0;
-            mids()[t] = 0;
+            store_ids(t, Ids{});
             ts()[t] = 0.0; tf()[t] = 0.0;
 #pragma unroll
             for (int j = 0; j < MC; j++) marr()[j * PT_ + t] = __builtin_nan("");  // empty member slots
@@ -954,7 +967,8 @@ struct Sim {
 #pragma unroll
         for (int i = 0; i < NAW; i++) mm.w[i] = 0;
         am_set(mm, leader);
-        uint64_t mlist = (uint64_t)(uint32_t)leader;                          // ordered member ids, byte j (task actions only)
+        Ids mlist{};                                                          // ordered member ids of this step, byte j (task actions only)
+        mlist.put(0, (uint32_t)leader);
         int nm = 1;
         double tx_, ty_;
         if (action == 0 && nfol_in < 0 && !no_grouping) {   // (individual selection: agent_step(agent, 0) moves that agent only)
@@ -989,7 +1003,7 @@ struct Sim {
                 }
                 am_clear(rest, f); rlen--;                                    // :332-333
                 am_set(mm, f);
-                mlist |= (uint64_t)(uint32_t)f << (8 * nm);
+                mlist.put(nm, (uint32_t)f);
                 nm++;
             }
             if (action == 0) { tx_ = ((const Hdr*)base)->depot_x; ty_ = ((const Hdr*)base)->depot_y; }
@@ -1039,19 +1053,17 @@ struct Sim {
             // 1..5 members in order; "already listed" is a SWAR byte search in the packed ordered id word.
             const int k = action - 1;
             const uint32_t info = uni(tinfo()[k]);
-            uint64_t ids = uni(mids()[k]);
+            Ids ids = load_ids(k);
+#pragma unroll
+            for (int i = 0; i < IW; i++) ids.w[i] = uni(ids.w[i]);
             int n = (info >> 16) & 0xFF;
             for (int j = 0; j < nm; j++) {
-                const int m = (int)((mlist >> (8 * j)) & 0xFF);
-                const uint64_t x = ids ^ (0x0101010101010101ull * (uint64_t)(uint32_t)m);
-                uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // lowest set bit = first zero byte
-                z &= (n >= 8) ? ~0ull : ((1ull << (8 * n)) - 1ull);
-                int pos;
-                if (z) pos = (__ffsll((unsigned long long)z) - 1) >> 3;
-                else {
+                const int m = (int)mlist.byte(j);
+                int pos = ids.find((uint32_t)m, n);
+                if (pos < 0) {
                     if constexpr (!DEV) { if (n >= MC) { h.flags |= DCM_FLAG_OVERFLOW | DCM_FLAG_DONE; return; } }
                     pos = n++;
-                    ids |= (uint64_t)(uint32_t)m << (8 * pos);                // bytes above n are always zero
+                    ids.put(pos, (uint32_t)m);                                // bytes above n are always zero
                 }
                 // the arrival was computed by agent m's own lane above: that lane stores it (no readlane round trip through
                 // the scalar unit, and the store does not wait for the sqrt chain of the other members)
@@ -1059,7 +1071,7 @@ struct Sim {
                 for (int i = 0; i < NAW; i++) if (i * WAVE + lane == m) marr()[pos * PT() + k] = arrv[i];
                 if (track && lane == 0) *dirty() |= (2u << pos) | DIRTY_IDS;
             }
-            if (lane == 0) { mids()[k] = ids; tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
+            if (lane == 0) { store_ids(k, ids); tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
         h.d += 1;
         WSYNC();
@@ -1524,13 +1536,13 @@ __global__ void k_get_members(int T, int PA, int PT, int PC, const unsigned char
     const int eT = sizes ? sizes[2 * e + 1] : T;
     const Lay L{PA, PT, PC};
     const unsigned char* rec = state + (size_t)e * L.rec_bytes();
-    uint64_t ids = 0;
+    uint64_t ids[2] = {0, 0};
     int n = 0;
     if (t < eT) {
-        ids = ((const uint64_t*)(rec + L.mids()))[t];
+        for (uint32_t w = 0; w < L.idw(); w++) ids[w] = ((const uint64_t*)(rec + L.mids()))[w * PT + t];
         n = (int)((((const uint32_t*)(rec + L.tinfo()))[t] >> 16) & 0xFF);
     }
-    for (int j = 0; j < PC; j++) ids_out[i * PC + j] = (j < n) ? (int16_t)((ids >> (8 * j)) & 0xFF) : (int16_t)-1;
+    for (int j = 0; j < PC; j++) ids_out[i * PC + j] = (j < n) ? (int16_t)((ids[j >> 3] >> (8 * (j & 7))) & 0xFF) : (int16_t)-1;
 }
 
 // task['abandoned_agent'] (env/task_env.py:89) as a dense count table: out[B][A][T] = number of times task t moved agent a to

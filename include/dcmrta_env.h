@@ -49,7 +49,7 @@ typedef enum {
 #define DCM_MAX_AGENTS 128
 #define DCM_MAX_TASKS 1023
 #define DCM_MAX_MEMBERS 5 /* COALITION_SIZE, parameters.py:17: members <= requirement <= 5 */
-#define DCM_MAX_MEMBERS_WIDE 8 /* member slots per task of a DCM_PARAM_WIDE_MEMBERS handle */
+#define DCM_MAX_MEMBERS_WIDE 16 /* member slots per task of a DCM_PARAM_WIDE_MEMBERS handle */
 #define DCM_FOLLOWER_COLS 4
 
 /* per-env flag bits reported by dcm_env_status */
@@ -88,11 +88,11 @@ typedef enum {
  * this flag such an action freezes the env with DCM_FLAG_BAD_ACTION instead (the policy contract gives masked actions
  * probability 0, attention.py:74-76: a runner can use it to catch a policy that does not). */
 #define DCM_PARAM_STRICT_MASK 4u
-/* dcm_params.flags: DCM_MAX_MEMBERS_WIDE (8) member slots per task instead of DCM_MAX_MEMBERS (5).  The reference's member lists
+/* dcm_params.flags: DCM_MAX_MEMBERS_WIDE (16) member slots per task instead of DCM_MAX_MEMBERS (5).  The reference's member lists
  * are unbounded (env/task_env.py:321-322): a policy that ignores the mask (worker.py:140) can send more agents to a task than it
- * requires, and generate_env takes any max_coalition_size (:71).  A wide handle simulates both up to eight listed members per
- * task (requirements 1..8 are accepted by dcm_load_instances; a ninth member freezes the env with DCM_FLAG_OVERFLOW); its
- * records are 24 * T bytes larger, every shape runs the runtime-size kernels, dcm_get_members returns ids_out[B][T][8], and route
+ * requires, and generate_env takes any max_coalition_size (:71).  A wide handle simulates both up to sixteen listed members per
+ * task (requirements 1..16 are accepted by dcm_load_instances; a seventeenth member freezes the env with DCM_FLAG_OVERFLOW); its
+ * records are 96 * T bytes larger, every shape runs the runtime-size kernels, dcm_get_members returns ids_out[B][T][16], and route
  * replay (which has its own member_cap) is not available on it.  Injected follower lists still hold at most DCM_FOLLOWER_COLS. */
 #define DCM_PARAM_WIDE_MEMBERS 8u
 
