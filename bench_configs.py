@@ -289,7 +289,7 @@ def config6(B=4096):
     sync()
     warm.close()
     for name, (A, T) in (("20A50T exact <20,50>", (20, 50)), ("20A49T <20,50,runtime sizes>", (20, 49)),
-                         ("15A35T <20,50,runtime sizes>", (15, 35)), ("21A51T <64,64,runtime sizes>", (21, 51)), ("70A130T generic <0,0>", (70, 130))):
+                         ("15A35T <20,50,runtime sizes>", (15, 35)), ("21A51T <64,64,runtime sizes>", (21, 51)), ("70A130T mid-size <2,3 chunks>", (70, 130))):
         env = BatchedTaskEnv(B, A, T, device=DEV).load_instances(**generate_batch(B, A, T, 0))
         seeds = env_seeds(0, 0, B)
         env.reset(seeds, observe=False)

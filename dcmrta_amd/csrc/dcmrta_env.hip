@@ -1450,6 +1450,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
 #include "rollout_fast.hpp"
 #include "step_fast.hpp"
 #include "rollout_fast_mc.hpp"
+#include "rollout_fast_g.hpp"
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, int PC, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
@@ -1865,6 +1866,22 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
         if (all_obs) { CALLM(true); } else { CALLM(false); }
 #undef CALLM
+        LAUNCH_OK();
+        return DCM_OK;
+    }
+    // Every other batch of the mid-size class (A <= 128, T <= 256; uniform or ragged): rollout_fast_g.hpp, chunk counts from the batch dims
+    if (env->L.C == M && env->A <= 128 && env->T <= 256 && !(env->L.A == 20 && env->L.T == 50) && !(env->L.A == 64 && env->L.T == 64) &&
+        (all_obs || no_obs)) {
+#define CALLG(NAC, NTC, OBS)                                                                                           \
+    hipLaunchKernelGGL((k_rollout_fast_g<NAC, NTC, OBS>), GRID(env), (Sim<128, 256, true>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, \
+                       DIMS(env), env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
+                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
+#define CALLT(NAC, OBS) do { if (env->T > 192) { CALLG(NAC, 4, OBS); } else if (env->T > 128) { CALLG(NAC, 3, OBS); } else { CALLG(NAC, 2, OBS); } } while (0)
+#define CALLA(OBS) do { if (env->A > 64) { CALLT(2, OBS); } else { CALLT(1, OBS); } } while (0)
+        if (all_obs) { CALLA(true); } else { CALLA(false); }
+#undef CALLA
+#undef CALLT
+#undef CALLG
         LAUNCH_OK();
         return DCM_OK;
     }

@@ -105,11 +105,14 @@ def issue_roofline(c, units_per_step, step_s, unit="decision"):
 
 def rollout_kernel_name(A, T):
     """Which persistent rollout kernel dcm_rollout_random launches for a uniform batch of this shape (all three observation
-    buffers given): the register-resident kernels for the one-chunk layouts and for 50A/200T, the general one otherwise."""
+    buffers given): the register-resident kernels for the one-chunk layouts, for 50A/200T and for the mid-size class (A <= 128,
+    T <= 256), the general one otherwise."""
     if A <= 64 and T <= 63:
         return "k_rollout_fast"
     if (A, T) == (50, 200):
         return "k_rollout_fast_mc"
+    if A <= 128 and T <= 256 and not (A <= 64 and T <= 64):
+        return "k_rollout_fast_g"
     return "k_rollout_random"
 
 

@@ -50,11 +50,13 @@ def _check_last_decision(env, refs, taken, tag, ran=None):
         assert np.array_equal(mk2[b].astype(np.uint8), ref["mask"][k]), name
 
 
-@pytest.mark.parametrize("A,T,B,stops", [(20, 50, 48, 6), (50, 200, 32, 4), (15, 35, 32, 5), (12, 23, 16, 4), (33, 60, 12, 3), (70, 130, 6, 3)])
+@pytest.mark.parametrize("A,T,B,stops", [(20, 50, 48, 6), (50, 200, 32, 4), (15, 35, 32, 5), (12, 23, 16, 4), (33, 60, 12, 3), (70, 130, 6, 3),
+                                         (65, 65, 8, 3), (128, 256, 3, 2), (30, 100, 8, 3), (100, 64, 6, 3), (64, 192, 4, 2), (40, 64, 8, 3)])
 def test_per_decision_outputs_at_random_indices(gpu_device, oracle_lib, A, T, B, stops):
     """Stop every env after random decision indices (per-env budgets) and compare what the persistent kernel stored for
     that decision with the oracle's recorded rec_agents / rec_tasks / rec_mask (oracle/dcmrta_oracle.c:569-576); carry on;
-    finish.  Shapes: BASELINE configs 2 and 4, two training shapes (runtime sizes in the <20,50> layout), A > 64."""
+    finish.  Shapes: BASELINE configs 2 and 4, two training shapes (runtime sizes in the <20,50> layout), and the mid-size class of
+    rollout_fast_g.hpp: one / two agent chunks x two / three / four task chunks, T a multiple of 64 (no free lane for the depot)."""
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.choice import env_seeds
     from dcmrta_amd.instances import generate_batch
