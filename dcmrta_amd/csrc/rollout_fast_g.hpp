@@ -303,7 +303,7 @@ struct FastG {
                 const float f0 = (float)travel, f1 = (float)remaining, f2 = (float)waiting;
                 const float f3 = (float)(lx - r.ax[ac]), f4 = (float)(ly - r.ay[ac]), f5 = (r.ai[ac] & A_ASSIGNED) ? 1.f : 0.f;
                 if (in_agent(ac, lane)) {                                        // :176-177
-                    float* agrow = ag + 6 * (ac * 64 + lane);
+                    float* agrow = (ag + 6 * lane) + 6 * 64 * ac;                // (one per-lane base; the chunk offset is an immediate)
                     agrow[0] = f0; agrow[1] = f1; agrow[2] = f2; agrow[3] = f3; agrow[4] = f4; agrow[5] = f5;
                 }
             }
@@ -327,9 +327,8 @@ struct FastG {
                 const float g0 = (float)(int)(int8_t)((info >> 8) & 0xFF), g1 = (float)(info & 0xFF), g2 = r.durf[c];
                 const float g3 = (float)(r.tx[c] - lx), g4 = (float)(r.ty[c] - ly);   // :185-188
                 if (in_task(c, lane)) {
-                    const int rowi = c * 64 + lane + 1;                          // (32-bit offsets from the wave-uniform bases)
-                    mk[rowi] = mv;
-                    float* row = tk + 5 * rowi;
+                    (mk + lane)[c * 64 + 1] = mv;
+                    float* row = (tk + 5 * lane) + 5 * (c * 64 + 1);
                     row[0] = g0; row[1] = g1; row[2] = g2; row[3] = g3; row[4] = g4;
                 }
             }
@@ -462,7 +461,8 @@ struct FastG {
         for (int ac = 0; ac < NAC; ac++) {
             const bool mem = (mm[ac] >> lane) & 1ull;
             if (mem) {
-                S.tdist()[ac * 64 + lane] += d[ac];                              // :317 (read by the terminal metrics only)
+                // :317 travel_dist += d: read by the terminal metrics only, so an LDS atomic (same IEEE addition, no round trip to wait for)
+                __hip_atomic_fetch_add(&S.tdist()[ac * 64 + lane], d[ac], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 r.arr[ac] = arrv[ac];
                 r.ax[ac] = tx_; r.ay[ac] = ty_;                                  // :320
                 r.cur[ac] = k;                                                   // :314

@@ -47,15 +47,17 @@ struct FastM {
     struct R {
         double ax, ay, arr, nd, td;                    // agent: location, arrival_time[-1], next_decision, travel_dist
         int32_t cur; uint32_t ai;                      //        route[-1], ainfo word
-        double cts, ctf, cdur; bool cfeas;             //        time_start / time_finish / duration / feasible flag of route[-1]
-        uint32_t ti[NTC]; double tf[NTC];              // task (per chunk): tinfo word, time_finish
+        double cts, cend; bool cfeas;                  //        of route[-1]: time_start, time_start + duration (== time_finish once it
+                                                       //        is feasible; 0.0 + duration before), feasible flag
+        uint32_t ti[NTC];                              // task (per chunk): tinfo word
         uint64_t ids[NTC];                             //        ordered member ids
         double tx[NTC], ty[NTC]; float durf[NTC];      //        instance (depot lane of the last chunk: depot x, y, 0); the duration as
                                                        //        the observation holds it (the fp64 value stays in the LDS image)
     };
-    // Not in registers (the kernel needs three waves per SIMD): time_start -- written once, when the task becomes feasible, read
-    // by nobody on the fast path (the agents get it broadcast at that moment) -- sits in f64[T] of LDS behind the image; the
-    // wake-up times use the image's own f32[T] array, which the arrival slots do not cover.
+    // Not in registers (the kernel needs three waves per SIMD): time_start -- written once, when the task becomes feasible -- sits in
+    // f64[T] of LDS behind the image; time_finish is not stored at all on the fast path: it is time_start + duration (:256-257, the
+    // same fp64 addition) for a feasible task and the 0.0 of clear_decisions (:131) otherwise.  The wake-up times use the image's
+    // own f32[T] array, which the arrival slots do not cover.
     __device__ __forceinline__ double* ts_x() const { return (double*)(S.base + SimT::lds_image_bytes(L)); }
     static constexpr uint32_t LDS_BYTES = SimT::lds_image_bytes(Lay{CA, CT}) + 8u * CT + 512u;   // + the removal path's dummy slots
 
@@ -93,12 +95,12 @@ struct FastM {
         r.ax = S.ax()[la]; r.ay = S.ay()[la]; r.arr = S.arr()[la]; r.nd = S.nd()[la]; r.td = S.tdist()[la];
         r.cur = S.cur()[la]; r.ai = S.ainfo()[la];
         const int K = r.cur < 0 ? 0 : r.cur;
-        r.cts = S.ts()[K]; r.ctf = S.tf()[K]; r.cdur = S.tdur()[K]; r.cfeas = S.tinfo()[K] & T_FEAS;
+        r.cts = S.ts()[K]; r.cend = r.cts + S.tdur()[K]; r.cfeas = S.tinfo()[K] & T_FEAS;
         int ninf = 0;
 #pragma unroll
         for (int c = 0; c < NTC; c++) {
             const int t = tidx(c, lane);
-            r.ti[c] = S.tinfo()[t]; r.tf[c] = S.tf()[t]; r.ids[c] = S.mids()[t];
+            r.ti[c] = S.tinfo()[t]; r.ids[c] = S.mids()[t];
             if (in_task(c, lane)) { ts_x()[t] = S.ts()[t]; S.wake()[t] = -__builtin_inff(); }   // every chunk is due at the next new event
             ninf += __popcll(__ballot(!(r.ti[c] & T_FEAS)) & tmask(c));
         }
@@ -126,7 +128,8 @@ struct FastM {
 #pragma unroll
         for (int c = 0; c < NTC; c++) if (in_task(c, lane)) {
             const int t = c * 64 + lane;
-            S.tinfo()[t] = r.ti[c]; S.ts()[t] = ts_x()[t]; S.tf()[t] = r.tf[c]; S.mids()[t] = r.ids[c];
+            const double ts_ = ts_x()[t];
+            S.tinfo()[t] = r.ti[c]; S.ts()[t] = ts_; S.tf()[t] = (r.ti[c] & T_FEAS) ? ts_ + S.tdur()[t] : 0.0; S.mids()[t] = r.ids[c];
         }
         if (lane == 0) S.inc_state()[1] = -1;          // the general code's own incremental state: next call visits every task
         WSYNC();
@@ -144,7 +147,8 @@ struct FastM {
         double av[M];
 #pragma unroll
         for (int j = 0; j < M; j++) av[j] = slots()[j * CT + t];                 // :251 (unused slots hold NaN)
-        const double tfin = r.tf[C], dur = S.tdur()[t];                           // (the image's duration section is never covered)
+        const double dur = S.tdur()[t];                                          // (the image's duration section is never covered)
+        const double tfin = feas0 ? ts_x()[t] + dur : 0.0;                       // time_finish (see R)
         const int status = req - n;                                              // :252
         double mx = av[0], mn = av[0];
 #pragma unroll
@@ -154,7 +158,7 @@ struct FastM {
         const double thr = mx - mwt;                                             // :262
         const bool any_drop = inT && !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
         const bool becomes = inT && !feas0 && ok;                                // :256-258
-        const double ntf = becomes ? mx + dur : tfin;
+        const double ntf = mx + dur;                                             // time_finish if it becomes feasible now
         if (becomes) ts_x()[t] = mx;                                             // time_start :256
         int nn = n;
         const uint64_t dmask = __ballot(any_drop);
@@ -216,7 +220,7 @@ struct FastM {
         const uint32_t info_i = ((info | (ok ? T_FEAS : 0u)) & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
         const uint32_t info_f = info | ((now >= tfin) ? T_FIN : 0u);             // :273-274
         info = feas0 ? info_f : info_i;
-        r.ti[C] = info; r.tf[C] = ntf;
+        r.ti[C] = info;
         // when can the time alone change this task next?  (see Sim::task_update)
         double w = (info & T_FEAS) ? ((info & T_FIN) ? __builtin_inf() : (feas0 ? tfin : mx + dur)) : mn + mwt;
         w = (w == w) ? w : __builtin_inf();
@@ -228,7 +232,7 @@ struct FastM {
             const int b = __ffsll((unsigned long long)bmask) - 1;
             bmask &= bmask - 1ull;
             const double ts_k = rl(mx, b), tf_k = rl(ntf, b);
-            if (r.cur == C * 64 + b) { r.cfeas = true; r.cts = ts_k; r.ctf = tf_k; }
+            if (r.cur == C * 64 + b) { r.cfeas = true; r.cts = ts_k; r.cend = tf_k; }
         }
         // a freshly feasible task only changes again at this `now` if it is already over (:273 is evaluated one call later)
         if (__ballot(any_drop || (becomes && now >= mx + dur))) touched_out |= 1u << C;
@@ -258,7 +262,7 @@ struct FastM {
     __device__ __forceinline__ void agent_update(R& r, double now, double mwt) const {
         const int c = r.cur;
         const bool member = r.cfeas && (r.ai & A_MEMBER);                        // :229-230
-        const double ndv = (c == -1) ? __builtin_nan("") : (member ? r.ctf : r.arr + mwt);   // :226,:231,:235,:238
+        const double ndv = (c == -1) ? __builtin_nan("") : (member ? r.cend : r.arr + mwt);   // :226,:231,:235,:238
         const uint32_t as = member ? ((r.ai & A_ASSIGNED) | ((now >= r.cts) ? A_ASSIGNED : 0u)) : 0u;   // :232-240
         r.nd = (c != -2) ? ndv : r.nd;                                           // :209
         r.ai = (c >= 0) ? ((r.ai & ~A_ASSIGNED) | as) : r.ai;                    // depot leaves `assigned` untouched (Q6)
@@ -273,7 +277,7 @@ struct FastM {
         const double lx = rl(r.ax, leader), ly = rl(r.ay, leader);
         if constexpr (OBS) {
             const bool on = r.cur >= 0;                                          // :168
-            const double x = r.arr - now, w = now - r.arr, rem = r.cts + r.cdur - now;
+            const double x = r.arr - now, w = now - r.arr, rem = r.cend - now;
             const double travel = (on && x > 0.) ? x : 0.;                       // :169
             const double waiting = (on && now <= r.cts && w > 0.) ? w : 0.;      // :170
             const double remaining = (on && now >= r.cts && rem > 0.) ? rem : 0.;   // :171
@@ -302,9 +306,9 @@ struct FastM {
                 const float g0 = (float)(int)(int8_t)((info >> 8) & 0xFF), g1 = (float)(info & 0xFF), g2 = r.durf[c];
                 const float g3 = (float)(r.tx[c] - lx), g4 = (float)(r.ty[c] - ly);   // :185-188
                 if (in_task(c, lane) || dep) {
-                    const int rowi = dep ? 0 : c * 64 + lane + 1;                // (32-bit offsets from the wave-uniform bases)
-                    uint8_t* mp = mk + rowi;
-                    float* row = tk + 5 * rowi;
+                    // (one per-lane base for every chunk, the chunk offset is an instruction immediate; the depot lane writes row 0)
+                    uint8_t* mp = dep ? mk : (mk + lane) + (c * 64 + 1);
+                    float* row = dep ? tk : (tk + 5 * lane) + 5 * (c * 64 + 1);
                     *mp = mv;
                     row[0] = g0; row[1] = g1; row[2] = g2; row[3] = g3; row[4] = g4;
                 }
@@ -415,7 +419,7 @@ struct FastM {
                 slots()[slot * CT + k] = arrv;
                 // the new current task as agent_update / the observation read it: a task the device policy can pick is not feasible
                 // yet, and time_start / time_finish of such a task are still the 0.0 of clear_decisions (:131, set at :256-257)
-                r.cfeas = false; r.cts = 0.0; r.ctf = 0.0; r.cdur = dur_k;
+                r.cfeas = false; r.cts = 0.0; r.cend = 0.0 + dur_k;
             }
         }
         if (kc >= 0 && lane == tl) {
