@@ -198,22 +198,25 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
 
 def other_config_shards(dev, visibility, passes=4):
     """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 8192 envs x
-    100A/500T route replay with dynamic arrivals), timed inside the DEFAULT run so that whoever clocks `python bench.py` also
+    100A/500T route replay with dynamic arrivals), and one mid-size shape (4096 envs x 70A/130T), timed inside the DEFAULT run so that whoever clocks `python bench.py` also
     clocks them: one warm pass, then `passes` passes back to back, one stream, inputs resident in HBM.  The full lines of these
     configs (roofline, cpu_baseline, sharding) are `bench.py --config 4` / `--config 5`."""
     out = {}
-    for name, cfg, B in (("config4_shard", CONFIGS["4"], 8192), ("config5_shard", CONFIGS["5"], 8192)):
+    mid = dict(CONFIGS["2"], agents=70, tasks=130, episodes=3)     # a mid-size shape (env/task_env.py:57-65 draws sizes from ranges)
+    for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
         A, T = cfg["agents"], cfg["tasks"]
         c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"])
         sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)
-        sb.run(1, True)
+        sb.run(eps, True)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        counts = [sb.run(1, True)[0] for _ in range(passes)]
+        counts = [sb.run(eps, True)[0] for _ in range(passes)]
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         n = int(torch.stack(counts).sum().item())
-        out[name] = {"workload": f"{B} envs x {A}A/{T}T, the per-GPU shard of {cfg['label']} on 8 GPUs", "kernel": c["kernel"],
+        what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
+            "random-policy rollout at a mid-size shape, 3 episodes per env per pass, one stream"
+        out[name] = {"workload": f"{B} envs x {A}A/{T}T, {what}", "kernel": c["kernel"],
                      "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes}
         sb.env.close()
     return out

@@ -163,6 +163,8 @@ def test_default_line_times_the_other_baseline_configs(gpu_device):
     assert oc["config4_shard"]["kernel"] == "k_rollout_fast_mc" and oc["config4_shard"]["value"] > 1e8
     assert 8192 * 200 < oc["config4_shard"]["steps_per_pass"] < 8192 * 500           # ~320 decisions per 50A/200T episode
     assert oc["config5_shard"]["kernel"] == "k_replay" and oc["config5_shard"]["value"] > 1e8
+    assert oc["midsize_70A130T"]["kernel"] == "k_rollout_fast_g" and oc["midsize_70A130T"]["value"] > 1e8
+    assert 4096 * 3 * 200 < oc["midsize_70A130T"]["steps_per_pass"] < 4096 * 3 * 500   # ~296 decisions per 70A/130T episode
     lk = j["lockstep_kernel"]
     assert lk["kernel"] == "k_step_fast" and 0.2 < lk["frac"] < 1.2 and (lk["traffic_frac"] is None or lk["traffic_frac"] < lk["frac"])
     assert j["cpu_baseline"]["value"] > 0 and j["value"] > 1e6

@@ -259,3 +259,31 @@ def test_return_log_keeps_every_episode(gpu_device, oracle_lib):
     assert not bool(obs.active.any())
     r2 = ring2.cpu().numpy()
     assert not np.isnan(r2).any() and np.array_equal(r2[:, 1], ls.summary()[:, 0].cpu().numpy())
+
+
+@pytest.mark.parametrize("A,T,B", [(20, 50, 16), (50, 200, 6), (70, 130, 6), (30, 100, 8), (128, 256, 2), (65, 64, 6)])
+def test_three_episodes_in_one_launch_against_the_oracle(gpu_device, oracle_lib, A, T, B):
+    """One launch plays three consecutive episodes per env (what a bench pass does): the decision counter keeps running across the
+    restarts, so episode k of env b is the oracle's rollout from d0 = the decisions of the episodes before it.  Every episode's
+    return (dcm_set_return_log), the step total, and the last episode's full terminal state must match -- through each
+    register-resident kernel (one chunk, 50A/200T, the mid-size class with one and two agent chunks)."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    inst = generate_batch(B, A, T, base_seed=4000 + A + T)
+    seeds = env_seeds(17, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device).load_instances(**inst)
+    ring = env.enable_return_log(3)
+    env.reset(seeds, observe=False)
+    steps = env.rollout_random(episodes=3).cpu().numpy()
+    got = ring.cpu().numpy()
+    fin = H.gpu_final(env)
+    for b in range(B):
+        d0, ref = 0, None
+        for k in range(3):
+            ref = oracle_lib.OracleEnv(A, T).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b]) \
+                .rollout(int(seeds[b]), d0, oracle_lib.POLICY_RANDOM, cap_steps=20000, record=False)
+            assert got[b, k] == ref["reward"], (b, k, got[b, k], ref["reward"])
+            d0 += ref["n_steps"]
+        assert steps[b] == d0, (b, steps[b], d0)
+        H.assert_final_matches(fin[b], ref, f"{A}A{T}T env{b} third episode")

@@ -223,8 +223,10 @@ def test_persistent_kernel_keeps_four_waves_per_simd(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     usage = {}
-    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", out.stderr, re.S):
+    spills = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)", out.stderr, re.S):
         usage[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+        spills[m.group(1)] = int(m.group(4))
     seen = 0
     for name, (vgprs, occ) in usage.items():
         # the persistent kernels of the one-chunk layouts (general and register-resident form, with the observation stores): all
@@ -236,7 +238,12 @@ def test_persistent_kernel_keeps_four_waves_per_simd(tmp_path):
         if "k_rollout_fast_mcILi50ELi200ELb1E" in name:                  # config 4: three waves per SIMD
             assert vgprs <= 168 and occ >= 3, (name, vgprs, occ)
             seen += 1
-    assert seen == 7, sorted(usage)
+        if "k_rollout_fast_gI" in name:                                   # the mid-size class: two waves per SIMD ...
+            assert occ >= 2, (name, vgprs, occ)
+            if "ILi2ELi3ELb1E" in name or "ILi1ELi2ELb1E" in name:       # ... without spills for the 70A/130T- and 30A/100T-class batches
+                assert spills[name] == 0, (name, spills[name])
+            seen += 1
+    assert seen == 7 + 12, sorted(usage)
 
 
 def test_synthetic_route_arrays_match_the_list_form():
@@ -283,3 +290,16 @@ def test_issue_roofline_pricing():
     r3 = R.issue_roofline(c3, 1e6, 1e-3)
     assert r3["bound"] == "salu_issue" and abs(r3["frac"] - 400 * 1.07 * 1e9 / (256 * 2.4e9)) < 1e-12 and r3["frac"] == r3["salu_issue_frac"]
     assert abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-12 and r3["valu_issue_frac"] <= r3["valu_issue_frac_hi"] < r3["frac"]
+
+
+def test_kernel_name_helpers_follow_the_dispatch():
+    """roofline.rollout_kernel_name / step_kernel_name (which rocprofv3 kernel a bench line is priced with) restate the shape
+    dispatch of dcm_rollout_random / dcm_step (csrc/dcmrta_env.hip): one-chunk layouts, 50A/200T, the mid-size class, the rest."""
+    from dcmrta_amd.roofline import rollout_kernel_name, step_kernel_name
+    assert rollout_kernel_name(20, 50) == rollout_kernel_name(15, 35) == rollout_kernel_name(64, 63) == "k_rollout_fast"
+    assert rollout_kernel_name(50, 200) == "k_rollout_fast_mc"
+    for shape in ((70, 130), (65, 65), (128, 256), (30, 100), (100, 64), (64, 65), (65, 10)):
+        assert rollout_kernel_name(*shape) == "k_rollout_fast_g", shape
+    for shape in ((64, 64), (100, 500), (50, 257), (128, 300)):     # T = 64 of the <64,64> layout has no free depot lane; larger shapes
+        assert rollout_kernel_name(*shape) == "k_rollout_random", shape
+    assert step_kernel_name(20, 50) == "k_step_fast" and step_kernel_name(70, 130) == "k_step" and step_kernel_name(64, 64) == "k_step"

@@ -9,7 +9,7 @@ python tools/collect_profile.py ${R}_c5 ${R}_config5 k_replay > /dev/null
 python tools/collect_profile.py ${R}_c5gen ${R}_config5_generalised k_replay > /dev/null
 python tools/collect_profile.py ${R}_c5static ${R}_config5_static k_replay > /dev/null
 python tools/collect_profile.py ${R}_15A35T ${R}_15A35T k_rollout_fast > /dev/null
-python tools/collect_profile.py ${R}_70A130T ${R}_70A130T k_rollout_random > /dev/null
+python tools/collect_profile.py ${R}_70A130T ${R}_70A130T k_rollout_fast_g > /dev/null
 python tools/collect_lockstep.py ${R}_lockstep 4096 20 50 > /dev/null
 python tools/collect_lockstep.py ${R}_lockstep 65536 20 50 > /dev/null
 python tools/collect_lockstep.py ${R}_lockstep 16384 50 200 > /dev/null
