@@ -41,6 +41,7 @@ struct Fast {
     SimT S;
     double* dummy;                                     // 64 doubles of LDS nobody reads (the removal path's discarded writes)
     mutable uint32_t dirty = 0;                        // TRK only
+    mutable bool calm = false;                         // the last task_update call left every task at a fixed point for its `now`
     uint64_t am, tm;                                   // lanes that own an agent / a task (wave-uniform masks)
     // per-lane constants
     bool inA, inT, isD;
@@ -84,6 +85,7 @@ struct Fast {
         r.ab = S.ablog() + la * AB_CAP;
     }
     __device__ __forceinline__ void reload(R& r) const {
+        calm = false;                                  // nothing is known about the general code's last call
         r.ax = S.ax()[la]; r.ay = S.ay()[la]; r.arr = S.arr()[la]; r.nd = S.nd()[la]; r.td = S.tdist()[la];
         r.cur = S.cur()[la]; r.ai = S.ainfo()[la];
         const int K = r.cur < 0 ? 0 : r.cur;
@@ -201,6 +203,9 @@ struct Fast {
         if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
         if constexpr (TRK) { if (__ballot(becomes && inT)) dirty |= SimT::DIRTY_TIMES; }
         const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
+        // (see Sim::task_update: a call can only change a task again at the same `now` if this one removed members or made a task
+        //  feasible that is already over)
+        calm = dmask == 0ull && __ballot(becomes && inT && now >= ntf) == 0ull;
         WSYNC();
         if (all_feasible) {                                                      // depot :277-280
             if ((r.ai & A_INDEPOT) && now >= r.arr) r.ai |= A_RETURNED;
@@ -341,9 +346,21 @@ struct Fast {
             r.ai = (r.ai & ~(A_GRP | A_MEMBER)) | (action == 0 ? A_INDEPOT : A_MEMBER);
             if (action) S.marr()[slot * CT + tl] = arrv;
         }
-        if (action && lane == tl) { r.ids = ids; r.lm |= mm; r.ti = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
+        // A QUIET join: the task still lacks members after it (status = requirement - len(members) > 0) and the previous
+        // task_update call -- at this same `now` -- left every task at a fixed point.  task_update (:245-281) then changes
+        // nothing but this task's status: not enough members -> not feasible (:254); the joining members have not waited
+        // (arrival >= now, :269); everybody else was evaluated at this `now` by the previous call.  The pass over the tasks is
+        // skipped and the task's lane takes the new status itself.
+        const int status_k = (int)(kinfo & 0xFFu) - n;
+        const bool quiet = action && calm && status_k > 0;
+        if (action && lane == tl) {
+            r.ids = ids; r.lm |= mm;
+            r.ti = quiet ? ((kinfo & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status_k & 0xFF) << 8) | ((uint32_t)n << 16))
+                         : ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16));
+            if (quiet) S.tinfo()[lt] = r.ti;                                     // (written through like task_update does)
+        }
         WSYNC();
-        task_update(r, now, P.mwt, lane);                                        // worker.py:74
+        if (!quiet) task_update(r, now, P.mwt, lane);                            // worker.py:74
         agent_update(r, now, P.mwt);                                             // worker.py:76
         return rlen;
     }

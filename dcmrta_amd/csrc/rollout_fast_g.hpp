@@ -475,12 +475,23 @@ struct FastG {
                 }
             }
         }
+        // A QUIET join (see FastM::decide): the task still lacks members and its lane chunk was at a fixed point for this `now` --
+        // the chunk visit is skipped, the task's lane takes the new status and pulls its wake-up time forward itself.
+        const int status_k = (int)(kinfo & 0xFFu) - n;
+        const bool quiet = kc >= 0 && status_k > 0 && !((touched >> (kc < 0 ? 0 : kc)) & 1u);
+        const float wj = __double2float_rd(rlc(arrv, leader >> 6, leader & 63) + P.mwt);   // (wave-uniform: a group arrives together)
         if (kc >= 0 && lane == tl) {
+            const uint32_t nti = quiet ? ((kinfo & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status_k & 0xFF) << 8) | ((uint32_t)n << 16))
+                                       : ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16));
 #pragma unroll
-            for (int c = 0; c < NTC; c++) if (c == kc) { r.ids[c] = ids; r.ti[c] = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
+            for (int c = 0; c < NTC; c++) if (c == kc) { r.ids[c] = ids; r.ti[c] = nti; }
+            if (quiet) {
+                float* wp = &S.wake()[k];
+                *wp = fminf(*wp, wj);
+            }
         }
         WSYNC();
-        task_update(r, now, P.mwt, lane, kc);                                    // worker.py:74
+        task_update(r, now, P.mwt, lane, quiet ? -1 : kc);                       // worker.py:74
         agent_update(r, now, P.mwt);                                             // worker.py:76
         return rlen;
     }

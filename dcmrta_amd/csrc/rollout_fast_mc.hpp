@@ -422,12 +422,28 @@ struct FastM {
                 r.cfeas = false; r.cts = 0.0; r.cend = 0.0 + dur_k;
             }
         }
+        // A QUIET join: the task still lacks members after it (status = requirement - len(members) > 0) and the previous
+        // task_update call -- at this same `now` -- left its lane chunk at a fixed point.  task_update (:245-281) then changes
+        // nothing but this task's status: not enough members -> not feasible (:254); the joining members have not waited
+        // (arrival >= now, :269); the members already listed were evaluated at this `now` by the previous call.  So the chunk
+        // visit is skipped: the task's lane takes the new status itself and pulls its wake-up time forward to the joiners'
+        // arrival + max_waiting_time (a group is co-located, so they all arrive when the leader does; a re-joining member may
+        // make the true time later: the bound stays conservative).
+        const int status_k = (int)(kinfo & 0xFFu) - n;
+        const bool quiet = kc >= 0 && status_k > 0 && !((touched >> (kc < 0 ? 0 : kc)) & 1u);
+        const float wj = __double2float_rd(rl(arrv, leader) + P.mwt);           // (wave-uniform)
         if (kc >= 0 && lane == tl) {
+            const uint32_t nti = quiet ? ((kinfo & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status_k & 0xFF) << 8) | ((uint32_t)n << 16))
+                                       : ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16));
 #pragma unroll
-            for (int c = 0; c < NTC; c++) if (c == kc) { r.ids[c] = ids; r.ti[c] = (kinfo & ~0x00FF0000u) | ((uint32_t)n << 16); }
+            for (int c = 0; c < NTC; c++) if (c == kc) { r.ids[c] = ids; r.ti[c] = nti; }
+            if (quiet) {
+                float* wp = &S.wake()[k];
+                *wp = fminf(*wp, wj);
+            }
         }
         WSYNC();
-        task_update(r, now, P.mwt, lane, kc);                                    // worker.py:74
+        task_update(r, now, P.mwt, lane, quiet ? -1 : kc);                       // worker.py:74
         agent_update(r, now, P.mwt);                                             // worker.py:76
         return rlen;
     }
