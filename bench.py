@@ -161,12 +161,14 @@ def cpu_baseline_replay(inst, routes, route_len, A, visibility, target_core_seco
                 single_thread_rate=n0 / dt0)
 
 
-def lockstep_kernel_probe(A, T, dev, B=65536, n=60, warm=40):
+def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
     """The lockstep kernel k_step really moves the algorithmic bytes (record in, record + observation out) once per
     decision: the HBM roofline of this path is quoted on it, at a batch that fills the machine, HIP events around
-    dcm_step only, device-side random policy; `warm` untimed steps first.  Runs right after the timed region, BEFORE the
-    CPU baseline: after seconds of host-only work the GPU has clocked down, and 40 steps (~10 ms) are over before it is
-    back at speed (BENCH_r03: 167 us median there against 137-143 us on a busy GPU).
+    dcm_step only, device-side random policy.  The window is the first ~100 decisions of an episode -- while every env is
+    still active -- because a step's cost depends on where the episode is: 138-150 us during the first 20 decisions at 20A/50T
+    (co-located groups decide several times per event), 162-170 us from decision 30 on (every decision ends its event).  The
+    committed rocprofv3 profile (tools/profile_lockstep.sh B A T 100) covers the same window.  Runs right after the timed
+    region, BEFORE the CPU baseline (after seconds of host-only work the GPU has clocked down).
     `frac` prices a launch with the ALGORITHMIC bytes W (the kernel skips clean sections, so this can exceed what
     HBM delivers); `traffic_frac` is the MEASURED HBM traffic of the committed profile of the same batch over the same time --
     the physical utilisation."""

@@ -12,9 +12,9 @@ bash tools/profile.sh ${R}_c4 --config 4 --envs 8192 --streams 1
 bash tools/profile.sh ${R}_c5 --config 5
 bash tools/profile.sh ${R}_c5gen --config 5 --visibility 100,100,10,500
 bash tools/profile.sh ${R}_c5static --config 5 --visibility static
-bash tools/profile_lockstep.sh 4096 20 50 80
-bash tools/profile_lockstep.sh 65536 20 50 40
-bash tools/profile_lockstep.sh 16384 50 200 40
+bash tools/profile_lockstep.sh 4096 20 50 100
+bash tools/profile_lockstep.sh 65536 20 50 100
+bash tools/profile_lockstep.sh 16384 50 200 100
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 python bench.py --config 4 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config4.json 2>> gpurun_out/${R}_bench.err
 python bench.py --config 5 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config5.json 2>> gpurun_out/${R}_bench.err
