@@ -198,16 +198,137 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
     return out
 
 
+def _bits_equal(a, b):
+    """Per-env equality of two [B, ...] arrays; float64 by bit pattern."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    eq = (a.view(np.uint64) == b.view(np.uint64)) if a.dtype == np.float64 else (a == b)
+    return eq.reshape(len(a), -1).all(axis=1)
+
+
+def parity_rollout(sb, A, EP, cores):
+    """Oracle parity of one sub-batch AT BENCH SIZE, after the timed region: the envs restart from their seeds, play one pass
+    (EP episodes in the persistent kernel, observation stores on) and every env's decision total, every episode's return
+    (dcm_set_return_log), last-episode reward, finished-task count and six perf metrics are compared bit for bit with the
+    multi-threaded oracle on the same instances / seeds (worker.py:45-87,103-108).  Returns (envs, mismatching envs, oracle
+    decisions, oracle seconds)."""
+    import oracle
+    oracle.build()
+    sb.env.reset(sb.seeds, observe=False)
+    steps = sb.env.rollout_random(episodes=EP, write_obs=True).cpu().numpy()
+    sm = sb.env.summary().cpu().numpy()
+    ring = sb.ring.cpu().numpy()
+    t0 = time.perf_counter()
+    ref = oracle.batch_rollout_full(sb.inst["depot"], sb.inst["task_xy"], sb.inst["req"], sb.inst["dur"], sb.seeds, A,
+                                    episodes=EP, threads=cores)
+    dt = time.perf_counter() - t0
+    ok = _bits_equal(steps, ref["steps"]) & _bits_equal(ring, ref["returns"]) & _bits_equal(sm[:, 0], ref["reward"]) & \
+        _bits_equal(sm[:, 1].astype(np.int32), ref["n_finished"]) & _bits_equal(sm[:, 2:8], ref["metrics"])
+    return sb.B, int((~ok).sum()), ref["total"], dt
+
+
+def parity_replay(sb, A, visibility, cores, max_envs=4096):
+    """The same for route replay: the first `max_envs` envs of the sub-batch through the oracle's execute_by_route (same routes,
+    same visibility schedule): agent_step totals, reward, finished-task count, six perf metrics, guard flag."""
+    import oracle
+    oracle.build()
+    n = min(sb.B, max_envs)
+    out = sb.env.execute_routes(sb.reactive, fields=())
+    steps, flags, sm = out["steps"].cpu().numpy()[:n], out["flags"].cpu().numpy()[:n], out["summary"].cpu().numpy()[:n]
+    t0 = time.perf_counter()
+    ref = oracle.batch_replay(sb.inst["depot"][:n], sb.inst["task_xy"][:n], sb.inst["req"][:n], sb.inst["dur"][:n], sb.routes[:n],
+                              sb.route_len[:n], reactive=sb.reactive, visibility=visibility, threads=cores)
+    dt = time.perf_counter() - t0
+    ok = _bits_equal(steps, ref["steps"]) & _bits_equal(sm[:, 0], ref["reward"]) & _bits_equal(sm[:, 1].astype(np.int32), ref["n_finished"]) & \
+        _bits_equal(sm[:, 2:8], ref["metrics"]) & (((flags & 4) != 0) == (ref["status"] == 1)) & ((flags & 0x58) == 0)
+    return n, int((~ok).sum()), ref["total"], dt
+
+
+PARITY_FIELDS_ROLLOUT = ["decisions per env", "return of every episode of the pass", "last-episode reward", "finished tasks",
+                         "success_rate, makespan, time_cost, waiting_time, travel_dist, efficiency"]
+PARITY_FIELDS_REPLAY = ["agent_step calls per env", "reward", "finished tasks", "six perf metrics", "guard / error flags"]
+
+
+def shard_roofline(kernel, A, T, units_per_pass, pass_s):
+    """Issue roofline of an other_configs entry from the committed counters of that kernel (profiles/counters.json)."""
+    c = load_counters(f"{kernel}:{A}A{T}T")
+    if not c:
+        return {"kernel": kernel, "frac": None, "note": f"no PMC profile committed for {kernel}:{A}A{T}T"}
+    r = issue_roofline(c, units_per_pass, pass_s, unit="decision")
+    keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_hi", "valu_issue_frac", "salu_issue_frac")
+            if r.get(k) is not None}
+    t = c.get("hbm_bytes_per_decision")
+    keep.update({"kernel": kernel, "traffic": t * units_per_pass if t is not None else None,
+                 "hbm_frac": (t * units_per_pass / pass_s / HBM_PEAK_BYTES_PER_S) if t is not None else None,
+                 "counters_source": c.get("source"), "stale": staleness(c, _lib.build_id())})
+    return keep
+
+
+def config3_probe(dev, B=4096, A=20, T=50, warm=30, n=150):
+    """BASELINE configs[2]: the attention policy (the stand-in of dcmrta_amd/policy.py: the reference's architecture, stock
+    PyTorch-ROCm ops, the reference's fp32 arithmetic) in the loop with the HIP env step -- worker.py:62-76 as one captured HIP
+    graph per decision (policy forward, sampling, dcm_step with the fused next observation), envs auto-resetting so that the
+    batch stays full.  Policy-bound and out of scope to tune (attention.py stays the consumer's): on the line because it is a
+    BASELINE config and the only workload where the observations this env writes are consumed."""
+    from dcmrta_amd.graph_rollout import GraphedRollout
+    from dcmrta_amd.policy import AttentionNet
+    torch.manual_seed(0)
+    net = AttentionNet().to(dev).eval()
+    net.assume_no_padding = True
+
+    @torch.no_grad()
+    def policy(ob):
+        lp = net(ob.tasks, ob.agents, ob.mask)                       # Categorical(logp.exp()).sample() as an exponential race
+        return torch.argmax(lp - torch.empty_like(lp).exponential_(1.0).log(), dim=1).to(torch.int32)
+    env = BatchedTaskEnv(B, A, T, device=str(dev), auto_reset=True).load_instances(**generate_batch(B, A, T, base_seed=0))
+    seeds = env_seeds(0, 0, B)
+    g = GraphedRollout(env, policy, check_every=8)
+    g.capture(seeds)
+    obs = env.reset(seeds)
+    for _ in range(warm):
+        g.graph.replay()
+    d0 = int(env.status()["decisions"].sum())
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.graph.replay()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    dec = int(env.status()["decisions"].sum()) - d0
+    # the env's share: HIP events around eager dcm_step calls on the same batch
+    ev = []
+    for _ in range(40):
+        act = torch.argmax((~obs.mask).to(torch.int32), dim=1).int()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        obs = env.step(act)
+        e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize(dev)
+    env_ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+    out = {"workload": f"{B} envs x {A}A/{T}T, attention policy (stand-in, stock PyTorch-ROCm fp32 = the reference's policy arithmetic) "
+                       f"sampled in the loop + HIP env step, one HIP graph per decision, auto-reset (BASELINE configs[2])",
+           "steps_per_s_end_to_end": dec / wall, "value": dec / wall, "unit": "steps/s", "batched_steps": n,
+           "ms_per_batched_step": wall / n * 1e3, "env_ms_per_batched_step": env_ms, "policy_share": 1 - env_ms / (wall / n * 1e3),
+           "active_fraction": dec / (n * B), "policy_dtype": "fp32",
+           "note": "policy-bound, out of scope: the env step is the HIP product, the policy is the consumer's (attention.py unchanged)"}
+    env.close()
+    return out
+
+
 def other_config_shards(dev, visibility, passes=4):
     """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 8192 envs x
-    100A/500T route replay with dynamic arrivals), and one mid-size shape (4096 envs x 70A/130T), timed inside the DEFAULT run so that whoever clocks `python bench.py` also
-    clocks them: one warm pass, then `passes` passes back to back, one stream, inputs resident in HBM.  The full lines of these
-    configs (roofline, cpu_baseline, sharding) are `bench.py --config 4` / `--config 5`."""
+    100A/500T route replay with dynamic arrivals), one mid-size shape (4096 envs x 70A/130T) and BASELINE configs[2] (attention
+    policy in the loop), timed inside the DEFAULT run so that whoever clocks `python bench.py` also clocks them: one warm pass,
+    then `passes` passes back to back, one stream, inputs resident in HBM.  Each entry carries its issue roofline (committed
+    counters of that kernel), a CPU baseline (the oracle on the same shard, all usable cores) and the oracle parity of the
+    shard.  The full lines of these configs (sharding, streams) are `bench.py --config 4` / `--config 5`."""
     out = {}
+    cores = usable_cores()
     mid = dict(CONFIGS["2"], agents=70, tasks=130, episodes=3)     # a mid-size shape (env/task_env.py:57-65 draws sizes from ranges)
     for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
         A, T = cfg["agents"], cfg["tasks"]
-        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"])
+        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"], episodes=eps)
         sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)
         sb.run(eps, True)
         torch.cuda.synchronize(dev)
@@ -219,8 +340,19 @@ def other_config_shards(dev, visibility, passes=4):
         what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
             "random-policy rollout at a mid-size shape, 3 episodes per env per pass, one stream"
         out[name] = {"workload": f"{B} envs x {A}A/{T}T, {what}", "kernel": c["kernel"],
-                     "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes}
+                     "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes,
+                     "roofline": shard_roofline(c["kernel"], A, T, n / passes, dt / passes)}
+        if sb.replay:
+            ne, bad, units, osec = parity_replay(sb, A, visibility, cores)
+            fields = PARITY_FIELDS_REPLAY
+        else:
+            ne, bad, units, osec = parity_rollout(sb, A, eps, cores)
+            fields = PARITY_FIELDS_ROLLOUT
+        out[name]["parity"] = {"envs_checked": ne, "mismatches": bad, "fields": fields}
+        out[name]["cpu_baseline"] = {"value": units / osec, "unit": "steps/s", "cores": cores, "kind": "port",
+                                     "sample": f"{ne} envs of this shard, one pass ({units} steps), oracle C port, {cores} threads"}
         sb.env.close()
+    out["config3"] = config3_probe(dev)
     return out
 
 
@@ -269,7 +401,11 @@ def main():
     ap.add_argument("--visibility", default=None,
                     help="config 5: initial,batch,period,cap of the dynamic-arrival schedule (default: the reference's 20,20,10,100); "
                          "'static' = no dynamic arrivals at all (execute_by_route with reactive_planning False, every task routed)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a rank waits in process-group bring-up / a collective before it fails with a reason")
+    ap.add_argument("--launch-timeout", type=float, default=None,
+                    help="N > 1, self-launched: wall-clock limit of the whole job (dcmrta_amd/launch.py; default 1500 s, 0 = none)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline AND the bench-size parity check)")
     ap.add_argument("--no-lockstep-probe", action="store_true")
     ap.add_argument("--no-obs", action="store_true", help="skip the observation stores (ablation, not the metric)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -288,7 +424,8 @@ def main():
     if replay:
         EP = 1
 
-    ctx = DistContext.from_env(expected_world=args.gpus)
+    ctx = DistContext.from_env(expected_world=args.gpus, timeout_s=args.dist_timeout)
+    device_names = ctx.device_names()
     dev = ctx.device
     torch.cuda.set_device(dev)
     if cfg["scaling"] == "weak":
@@ -415,6 +552,25 @@ def main():
         else:
             flags = sb.env.status()["flags"].cpu().numpy()
             assert (flags & 0x138).sum() == 0, "env error flags set"
+    # (right after the timed region, before any host-only work lets the GPU clock down)
+    lockstep = lockstep_kernel_probe(A, T, dev) if (ctx.world == 1 and not args.no_lockstep_probe and not replay) else None
+    # Oracle parity at bench size (part of the cpu_baseline leg, after the timed region): every env of this rank's block.
+    parity = None
+    if not args.no_cpu_baseline:
+        cores = max(1, usable_cores() // ctx.world)
+        checked = bad = 0
+        for sb in subs:
+            ne, nb, _, _ = parity_replay(sb, A, visibility, cores) if replay else parity_rollout(sb, A, EP, cores)
+            checked, bad = checked + ne, bad + nb
+        checked, bad = ctx.sum_over_ranks(checked), ctx.sum_over_ranks(bad)
+        parity = {"envs_checked": checked, "mismatches": bad, "fields": PARITY_FIELDS_REPLAY if replay else PARITY_FIELDS_ROLLOUT,
+                  "against": "oracle/ (C restatement of env/task_env.py + worker.py:45-87, pinned on reference-generated goldens), "
+                             "same instances / seeds" + (" / routes" if replay else "") + ", one pass after the timed region",
+                  "note": (f"first {min(subs[0].B, 4096)} envs of each rank's block" if replay else "every env of every rank's block")}
+        if bad:
+            print(f"bench.py: PARITY FAILURE: {bad} of {checked} envs differ from the oracle", file=sys.stderr, flush=True)
+            ctx.shutdown()
+            sys.exit(3)
     if ctx.rank != 0:
         ctx.shutdown()
         return
@@ -432,7 +588,7 @@ def main():
         # no profile committed for this very shape: price it with the instruction counts of the profiled shape that runs the same
         # kernel (the per-decision counts of one kernel move by a few per cent with the shape: 406 vs 413 VALU at 20A/50T vs
         # 15A/35T), and say so in the line
-        for key in {"k_rollout_fast": ("k_rollout_fast:20A50T",), "k_rollout_random": ("k_rollout_random:70A130T",)}.get(cfg["kernel"], ()):
+        for key in {"k_rollout_fast": ("k_rollout_fast:20A50T",), "k_rollout_fast_g": ("k_rollout_fast_g:70A130T",)}.get(cfg["kernel"], ()):
             c = load_counters(key)
             if c is not None:
                 counters_shape = key.split(":", 1)[1]
@@ -488,14 +644,16 @@ def main():
                    "visibility": ("static" if static_replay else list(visibility)) if replay else None,
                    "sharding": f"env batch x{ctx.world}, no data-path collective"
                                + (f", one async all-gather of the {EP} episode return(s) of every env per pass" if ctx.active else ""),
-                   "dist_backend": ctx.backend or None, "world": ctx.world, "process_group_ranks": ctx.group_size(),
+                   "dist_backend": ctx.backend or None, "world": ctx.world, "process_group_ranks": ctx.group_size(), "rank_devices": device_names,
                    "self_launched": os.environ.get("DCM_SELF_LAUNCHED") is not None},
         "roofline": roof,
+        "parity": parity,
     }
-    if ctx.world == 1 and not args.no_lockstep_probe and not replay:
-        for sb in subs:
-            sb.env.close()
-        out["lockstep_kernel"] = lockstep_kernel_probe(A, T, dev)
+    out["config"]["limits"] = {"members_per_task": 5, "members_per_task_wide_handle": 16, "A": 128, "T": 1023,
+                               "note": "the reference's lists are unbounded (env/task_env.py:321-322); at its constants "
+                                       "(COALITION_SIZE 5, 20A/50T..100A/500T) none of these limits is reached"}
+    if lockstep is not None:
+        out["lockstep_kernel"] = lockstep
     # (only in the full default run: the profiling / A-B tools pass --no-lockstep-probe --no-cpu-baseline and must see one kernel)
     if ctx.world == 1 and args.config == "2" and not (args.no_other_configs or args.no_lockstep_probe or args.no_cpu_baseline) and \
             all(getattr(args, k) is None for k in ("envs", "agents", "tasks")):

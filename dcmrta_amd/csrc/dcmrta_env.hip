@@ -81,7 +81,8 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 // not copied into LDS at all: the kernel works on the marr section of the env's own HBM record (one wave owns the record; a
 // wave's global accesses are issued and served in order, so it sees its own stores, and the section is read only at the head of
 // task_update's chain and by the terminal metrics).  The sections behind it move up by MSH bytes in the LDS image.
-// MC: member slots per task (5; 8 on a DCM_PARAM_WIDE_MEMBERS handle, which always runs the <0,0> instantiation).
+// MC: member slots per task (5; 16 = DCM_MAX_MEMBERS_WIDE, two id words, on a DCM_PARAM_WIDE_MEMBERS handle, which always runs the
+// <0,0> instantiation).
 template <int CA, int CT, bool RS, bool MG = false, int MC = M>
 struct Sim {
     static_assert(MC == M || (MC == MW && CA == 0 && !MG), "wide member slots: runtime-size instantiation only");
@@ -312,6 +313,7 @@ struct Sim {
     __device__ __forceinline__ float* wake() const { return (float*)(base + aux_off() + 48); }    // f32[PT], INC kernels only
     // k_step only: which task sections this call has written (bit 0 time_start / time_finish, bits 1..MC member-arrival row j,
     // bit 20 member ids, bit 21 abandonment counts), so that the write-back can skip the rest (DIRTY_ALL after a reset)
+    static_assert(MC + 1 < 20, "dirty mask: bits 1..MC are the arrival rows, 20 / 21 the ids / abandonment counts");
     static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_ROWS = ((1u << MC) - 1u) << 1, DIRTY_IDS = 1u << 20, DIRTY_NAB = 1u << 21,
                               DIRTY_ALL = DIRTY_TIMES | DIRTY_ROWS | DIRTY_IDS | DIRTY_NAB;
     __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + aux_off() + 24); }
@@ -1590,7 +1592,7 @@ __global__ void k_distance(const double* ax, const double* ay, const double* bx,
     do {                                                                                               \
         const dcm_env* e_ = (env);                                                                     \
         const bool exact_ = !e_->sizes && e_->A == e_->L.A && e_->T == e_->L.T;                        \
-        if (e_->L.C > M) { CALL(0, 0, false, MW); }   /* DCM_PARAM_WIDE_MEMBERS: eight member slots, runtime-size code */ \
+        if (e_->L.C > M) { CALL(0, 0, false, MW); }   /* DCM_PARAM_WIDE_MEMBERS: sixteen member slots (two id words), runtime-size code */ \
         else if (e_->L.A == 20 && e_->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } } \
         else if (e_->L.A == 64 && e_->L.T == 64) { CALL(64, 64, true); }                               \
         else if (exact_ && e_->A == 50 && e_->T == 200) { CALL(50, 200, false); }                      \
@@ -1807,9 +1809,13 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (!actions) return fail(DCM_ERR_INVALID, "dcm_step: null actions");
     if ((nfol_in == nullptr) != (followers_in == nullptr))
         return fail(DCM_ERR_INVALID, "dcm_step: nfol_in and followers_in must be given together");
+    // The register-resident kernels skip the task_update pass of a QUIET join on the ground that a member who has just joined
+    // has not waited max_waiting_time yet (env/task_env.py:269), which needs max_waiting_time > 0 (the reference's 10 / 100):
+    // a handle with max_waiting_time <= 0 (or NaN) takes the general kernels, which evaluate the rule literally.
+    const bool quiet_ok = env->kp.mwt > 0.0;
 #ifndef DCM_NO_FAST_STEP
     // The plain call shape on a one-chunk layout: the register-resident step (step_fast.hpp); same contract, same results.
-    if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
+    if (quiet_ok && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
         mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
 #define CALL(CA, CT, RS)                                                                                             \
     hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), env->kp, \
@@ -1839,11 +1845,12 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
+    const bool quiet_ok = env->kp.mwt > 0.0;     // (see dcm_step)
 #ifndef DCM_NO_FAST_ROLLOUT
     // One-chunk layouts (one lane per agent and per task, lane 63 free for the depot) with all three observation buffers or
     // none: the register-resident kernel.  Same contract, same results (tests/test_gpu_rollout.py runs both).
     const bool all_obs = agents_out && tasks_out && mask_out, no_obs = !agents_out && !tasks_out && !mask_out;
-    if (env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
+    if (quiet_ok && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
 #define CALLF(CA, CT, RS, OBS)                                                                                        \
     hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS>), GRID(env),                                                  \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), \
@@ -1859,7 +1866,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
         return DCM_OK;
     }
     // BASELINE configs[3], 50A/200T exactly: the multi-chunk register-resident kernel (rollout_fast_mc.hpp)
-    if (env->L.C == M && !env->sizes && env->A == 50 && env->T == 200 && env->L.A == 50 && env->L.T == 200 && (all_obs || no_obs)) {
+    if (quiet_ok && env->L.C == M && !env->sizes && env->A == 50 && env->T == 200 && env->L.A == 50 && env->L.T == 200 && (all_obs || no_obs)) {
 #define CALLM(OBS)                                                                                                    \
     hipLaunchKernelGGL((k_rollout_fast_mc<50, 200, OBS>), GRID(env), (FastM<50, 200, OBS>::LDS_BYTES), (hipStream_t)stream, \
                        DIMS(env), env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
@@ -1870,7 +1877,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
         return DCM_OK;
     }
     // Every other batch of the mid-size class (A <= 128, T <= 256; uniform or ragged): rollout_fast_g.hpp, chunk counts from the batch dims
-    if (env->L.C == M && env->A <= 128 && env->T <= 256 && !(env->L.A == 20 && env->L.T == 50) && !(env->L.A == 64 && env->L.T == 64) &&
+    if (quiet_ok && env->L.C == M && env->A <= 128 && env->T <= 256 && !(env->L.A == 20 && env->L.T == 50) && !(env->L.A == 64 && env->L.T == 64) &&
         (all_obs || no_obs)) {
 #define CALLG(NAC, NTC, OBS)                                                                                           \
     hipLaunchKernelGGL((k_rollout_fast_g<NAC, NTC, OBS>), GRID(env), (Sim<128, 256, true>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, \

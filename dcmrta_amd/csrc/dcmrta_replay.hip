@@ -756,6 +756,8 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
 #endif
 }
 
+#include "replay_fast.hpp"
+
 }  // namespace
 
 extern "C" {
@@ -815,6 +817,30 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     const uint32_t lds = slds ? lds_in : replay_lds_bytes(env->A, env->T, env->member_cap, false);
 
     RP P{100.0, 200.0, reactive ? 1 : 0, env->vis[0], env->vis[1], env->vis[2], env->vis[3]};  // env/task_env.py:564-565,567
+    // The register-resident kernel (replay_fast.hpp) for every replay whose agents fit two lane chunks, whose LIVE tasks -- all
+    // of them without dynamic arrivals, tasks 1..cap with them (an agent is never sent to a task that is not visible yet, and
+    // visible <= cap: env/task_env.py:567,578-584) -- fit two lane chunks and whose member slots fit one id word: BASELINE
+    // config 5 (100A/500T at the reference's cap of 100) and every small shape.  An explicit replay placement (1 / 2) asks for
+    // the general kernel, whose scratch block it places.
+    {
+        const int TL = reactive ? (env->T < env->vis[3] ? env->T : env->vis[3]) : env->T;
+        const uint32_t flds = replay_fast_lds_bytes(env->A, env->T, env->route_cap);
+        if (env->replay_placement == 0 && env->A <= 2 * WAVE && TL <= 2 * WAVE && env->member_cap <= 8 && flds <= 64u * 1024u) {
+#define REPLAYF(CMR, RE)                                                                                                     \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)k_replay_fast<2, 2, CMR, RE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds); \
+        hipLaunchKernelGGL((k_replay_fast<2, 2, CMR, RE>), GRID(env), flds, (hipStream_t)stream, env->A, env->T, TL, env->L.A, env->L.T, \
+                           env->member_cap, P, env->state, env->routes, env->route_len, env->route_cap, env->summary,      \
+                           steps_out, flags_out, finished, time_start, time_finish, task_wait, n_members, agent_wait,       \
+                           travel_dist, returned, env->gscratch);                                                          \
+    } while (0)
+            if (env->member_cap <= 5) { if (reactive) REPLAYF(5, true); else REPLAYF(5, false); }
+            else { if (reactive) REPLAYF(8, true); else REPLAYF(8, false); }
+#undef REPLAYF
+            LAUNCH_OK();
+            return DCM_OK;
+        }
+    }
 #define REPLAY(CA, CT, CMR, SL)                                                                                              \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)k_replay<CA, CT, CMR, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

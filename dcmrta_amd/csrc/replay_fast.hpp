@@ -1,0 +1,488 @@
+// replay_fast.hpp -- register-resident route replay (included by dcmrta_replay.hip, inside its anonymous namespace).
+//
+// execute_by_route (env/task_env.py:562-593) with every field the event loop touches in VGPRs, the design of the round-4 RL
+// kernels (rollout_fast*.hpp) applied to the replay:
+//
+//   * lane a of agent chunk i owns agent i*64 + a: position, arrival_time[-1], next_decision, travel_dist, max(arrival_time),
+//     route cursor + next preset action, route[-1], flags, and a CACHE of its current task's time_finish (NaN while that task is
+//     not feasible) -- so agent_update (:207-243) is lane-local arithmetic on all agents at once: the literal reference
+//     semantics (every agent, every call) for the price the LDS version paid for one agent;
+//   * lane t of task chunk c owns LIVE task c*64 + t: status word, ordered member ids (one byte each), the member arrival slots
+//     (NaN-padded: v_min/v_max_f64 ignore them), time_start / time_finish, duration, location, len(abandoned_agent) -- so
+//     task_update (:245-281) is lane-local select code on a whole chunk at once; only the removal of members (rare) runs a
+//     wave-uniform loop;
+//   * what the agent_step of agent a on task k reads "by index" is v_readlane from the owning lanes; its results go back
+//     through lane-select moves.  No LDS access, no HBM access and no s_waitcnt on the loop's critical path except the
+//     2-byte LDS read of the agent's next route entry;
+//   * LIVE tasks: the tasks that can ever get a member -- all T without dynamic arrivals; with them only tasks 1..vis_cap,
+//     because an agent is never sent to a task that is not visible yet (:578-584) and visible <= cap (:567).  At the
+//     reference's constants (cap 100) that is 2 lane chunks of a 100A/500T instance; the other 400 tasks stay as they were
+//     loaded (not feasible, no members) and only enter np.all(feasible) / np.all(finished) and the terminal metrics.
+//
+// Template: NAC agent chunks, NTL live task chunks, CMR member slots (bytes of one id word), REACTIVE = dynamic arrivals.
+// Sizes are runtime values (A <= 64 NAC, live tasks <= 64 NTL, member_cap <= CMR), so every replay of a small shape runs this
+// kernel too and the random parity sweeps exercise it.  LDS: the routes, int32[A][route_cap]; after the loop the same bytes
+// hold the terminal metrics' serial-sum inputs (f64[T] + 2 f64[A]).
+
+__device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+__host__ __device__ inline uint32_t replay_fast_lds_bytes(int A, int T, int route_cap) {
+    const uint32_t loop = (uint32_t)(4 * A * route_cap), term = (uint32_t)(8 * T + 16 * A);
+    return align16(loop > term ? loop : term);
+}
+
+template <int NAC, int NTL, int CMR, bool REACTIVE>
+__global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int PA, int PT, int MR, RP P, const unsigned char* state,
+                                                     const int32_t* routes, const int32_t* route_len, int route_cap,
+                                                     double* summary, int64_t* steps_out, uint32_t* flags_out,
+                                                     uint8_t* finished, double* time_start, double* time_finish,
+                                                     double* task_wait, int32_t* n_members, double* agent_wait,
+                                                     double* travel_dist, uint8_t* returned, unsigned char* gscr) {
+    static_assert(CMR <= 8, "member ids: one byte each of one 64-bit word");
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
+    const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
+    const double *gtx = (const double*)(rec + EL.tx()), *gty = (const double*)(rec + EL.ty()), *gtd = (const double*)(rec + EL.tdur());
+    const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
+    uint16_t* const gab = (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort());   // abandonment log u16[A][AB_CAP]
+    const Hdr* gh = (const Hdr*)rec;
+    const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
+    const int32_t* my_routes = routes + (size_t)e * A * route_cap;
+    int32_t* const lroute = (int32_t*)smem;
+    const double NaN = __builtin_nan("");
+#pragma nounroll
+    for (int i = lane; i < A * route_cap; i += WAVE) lroute[i] = my_routes[i];
+
+    // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance, into registers
+    uint32_t ti[NTL], nab[NTL];
+    uint64_t ids[NTL];
+    double tf[NTL], ts[NTL], dur[NTL], tx[NTL], ty[NTL], sl[NTL][CMR];
+#pragma unroll
+    for (int c = 0; c < NTL; c++) {
+        const int t = c * WAVE + lane, tt = t < TL ? t : 0;
+        const uint32_t req = t < TL ? (gti[tt] & 0xFFu) : 1u;                // lanes beyond the live tasks: an inert task
+        ti[c] = req | (req << 8); nab[c] = 0; ids[c] = 0;
+        tf[c] = 0.0; ts[c] = 0.0; dur[c] = gtd[tt]; tx[c] = gtx[tt]; ty[c] = gty[tt];
+#pragma unroll
+        for (int j = 0; j < CMR; j++) sl[c][j] = NaN;
+    }
+    double ax[NAC], ay[NAC], arr[NAC], nd[NAC], td[NAC], amx[NAC], ctf[NAC];
+    int nxt[NAC], cur[NAC], head[NAC], len[NAC];
+    uint32_t ai[NAC];
+#pragma unroll
+    for (int i = 0; i < NAC; i++) {
+        const int a = i * WAVE + lane, aa = a < A ? a : 0;
+        len[i] = a < A ? route_len[(size_t)e * A + aa] : -1;                  // pre_set_route :595-599 (-1 = None)
+        head[i] = 0;
+        nxt[i] = len[i] > 0 ? my_routes[(size_t)aa * route_cap] : 0;
+        ax[i] = depot_x; ay[i] = depot_y; arr[i] = 0.0; td[i] = 0.0; amx[i] = 0.0; ctf[i] = NaN;
+        nd[i] = a < A ? 0.0 : NaN;
+        cur[i] = -2; ai[i] = 0;
+    }
+    double now = 0.0;
+    uint32_t flags = 0;
+    bool finished_flag = false, redo = true;
+    int visible = 0, guard = 0, n_infeas = T, steps = 0;
+    const double mwt = P.mwt;                                                // :564
+    const int step_cap = 64 * (A + T) + 4096;                                // guard shared with the oracle (not in the reference)
+    WSYNC();
+
+    // ---- task_update (:245-281) of the live chunks `cm` (bit c), lane-local; returns through redo / n_infeas
+    auto task_update = [&](uint32_t cm) {
+        bool touched = false;
+#pragma unroll
+        for (int c = 0; c < NTL; c++) if ((cm >> c) & 1u) {
+            const uint32_t info = ti[c];
+            const bool feas = info & T_FEAS, fin = info & T_FIN;
+            const int req = info & 0xFF, n = (info >> 16) & 0xFF, status = req - n;     // :250-252
+            double mx = sl[c][0], mn = sl[c][0];
+#pragma unroll
+            for (int j = 1; j < CMR; j++) { mx = nanmax2(mx, sl[c][j]); mn = nanmin2(mn, sl[c][j]); }
+            const bool full = !feas && status <= 0;                          // :254
+            const bool ok = full && (mx - mn <= mwt);                        // :255
+            // members leave: the earliest arrival is <= max - mwt (:262) / has waited max_waiting_time (:269: now - v is the
+            // largest for the earliest member, and the first such member of the scan is always removed)
+            const bool rm = (full && !ok) || (!feas && status > 0 && (now - mn >= mwt));
+            const double tfin = mx + dur[c];
+            ts[c] = ok ? mx : ts[c]; tf[c] = ok ? tfin : tf[c];              // :256-258
+            const uint32_t ninfo = feas ? (info | ((!fin && now >= tf[c]) ? T_FIN : 0u))                  // :273-274
+                                        : ((info & (T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)n << 16) | (ok ? T_FEAS : 0u));
+            ti[c] = rm ? info : ninfo;
+            // only a task that is already over changes again at this `now` (finished, :273)
+            touched = touched || (ok && now >= tfin);
+            const uint64_t bm = __ballot(ok);
+            if (bm) {                                                        // became feasible (once per task)
+                n_infeas -= __popcll(bm);
+                // the agents standing at such a task cache its finish time (see agent_update)
+                for (uint64_t m = bm; m; m &= m - 1) {
+                    const int L = __ffsll((unsigned long long)m) - 1, k = c * WAVE + L;
+                    const double tfk = rl(tf[c], L);
+#pragma unroll
+                    for (int i = 0; i < NAC; i++) ctf[i] = cur[i] == k ? tfk : ctf[i];
+                }
+            }
+            uint64_t rmm = __ballot(rm);
+            if (rmm) {                                                       // :262-265 / :268-271, one task at a time, wave-uniform
+                touched = true;
+                for (; rmm; rmm &= rmm - 1) {
+                    const int L = __ffsll((unsigned long long)rmm) - 1, t = c * WAVE + L;
+                    const uint32_t inf = (uint32_t)rli((int)ti[c], L);
+                    uint64_t idw = rl64(ids[c], L);
+                    const int rq = inf & 0xFF, nn = (inf >> 16) & 0xFF, st = rq - nn;
+                    double sv[CMR];
+#pragma unroll
+                    for (int j = 0; j < CMR; j++) sv[j] = rl(sl[c][j], L);
+                    uint32_t drop = 0;
+                    if (st <= 0) {
+                        double m2 = sv[0];
+#pragma unroll
+                        for (int j = 1; j < CMR; j++) m2 = (j < nn && sv[j] > m2) ? sv[j] : m2;
+                        const double thr = m2 - mwt;                         // :262
+#pragma unroll
+                        for (int j = 0; j < CMR; j++) if (j < nn && sv[j] <= thr) drop |= 1u << j;
+                    } else {
+                        bool skip = false;                                   // remove-while-iterating (quirk Q1)
+#pragma unroll
+                        for (int j = 0; j < CMR; j++) if (j < nn) {
+                            if (skip) skip = false;
+                            else if (now - sv[j] >= mwt) { drop |= 1u << j; skip = true; }   // :269
+                        }
+                    }
+                    int left = nn;
+#pragma unroll
+                    for (int j = CMR - 1; j >= 0; j--) if ((drop >> j) & 1u) {
+                        const int id = (int)((idw >> (8 * j)) & 0xFFu);
+                        // abandoned_agent.append(id) :265/:271 -- the agent's own lane logs it
+#pragma unroll
+                        for (int i = 0; i < NAC; i++) if (i == (id >> 6)) {
+                            const bool me = lane == (id & 63);
+                            const uint32_t nth = ai[i] >> 16;
+                            if (me && nth < (uint32_t)AB_CAP) gab[id * AB_CAP + (int)nth] = (uint16_t)t;
+                            ai[i] = me ? ((ai[i] + (1u << 16)) & ((cur[i] == t) ? ~A_MEMBER : ~0u)) : ai[i];
+                        }
+                        // close the gap: slots j+1.. move down one
+#pragma unroll
+                        for (int q = j; q < CMR - 1; q++) sv[q] = sv[q + 1];
+                        sv[CMR - 1] = NaN;
+                        const uint64_t lowm = (j == 0) ? 0ull : (~0ull >> (64 - 8 * j));
+                        idw = (idw & lowm) | ((idw >> 8) & ~lowm);
+                        left--;
+                    }
+                    const bool me = lane == L;
+                    ids[c] = me ? idw : ids[c];
+#pragma unroll
+                    for (int j = 0; j < CMR; j++) sl[c][j] = me ? sv[j] : sl[c][j];
+                    nab[c] += me ? (uint32_t)(nn - left) : 0u;
+                    // (the status byte is the one computed BEFORE the removal: quirk Q3)
+                    ti[c] = me ? ((inf & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(st & 0xFF) << 8) | ((uint32_t)left << 16)) : ti[c];
+                }
+            }
+        }
+        redo = __any(touched);
+        if (n_infeas == 0) {                                                 // depot :277-280 (uniform; false until the very end)
+#pragma unroll
+            for (int i = 0; i < NAC; i++) ai[i] |= ((ai[i] & A_INDEPOT) && now >= arr[i]) ? A_RETURNED : 0u;
+        }
+    };
+    // ---- agent_update (:207-243, with the reactive depot branch :213-224) for every agent, lane-local
+    auto agent_update = [&]() {
+        bool allf_vis = false;
+        if constexpr (REACTIVE) {                                            // :214 all(feasible[:visible_length])
+            uint64_t inf = 0;
+#pragma unroll
+            for (int c = 0; c < NTL; c++) inf |= __ballot(c * WAVE + lane < visible && c * WAVE + lane < T && !(ti[c] & T_FEAS));
+            allf_vis = inf == 0;
+        }
+        bool terr = false;
+#pragma unroll
+        for (int i = 0; i < NAC; i++) {
+            const int c = cur[i];
+            double v;
+            uint32_t a2 = ai[i];
+            if constexpr (REACTIVE) {
+                const bool waits = !allf_vis && !(len[i] >= 0 && head[i] >= len[i]);          // :215-218
+                terr = terr || (c == -1 && waits && len[i] < 0);                               // :220 TypeError in the reference
+                const bool rearm = c == -1 && waits && len[i] >= 0;
+                const double vr = Rep::rearm_time(nxt[i], arr[i], now, P.vis_batch, P.vis_period);   // :221-222
+                a2 = rearm ? (a2 & ~A_INDEPOT) : a2;                                           // :223-224 depot['members'].remove
+                v = rearm ? vr : NaN;
+            } else {
+                v = NaN;                                                                       // :226
+            }
+            const bool member = (ctf[i] == ctf[i]) && (ai[i] & A_MEMBER);                      // :228-230
+            const double vt = member ? ctf[i] : arr[i] + mwt;                                  // :231 / :235,:238
+            v = c >= 0 ? vt : v;
+            nd[i] = c == -2 ? nd[i] : v;                                                       // :209 (an agent that never moved)
+            ai[i] = a2;
+        }
+        if constexpr (REACTIVE) { if (__any(terr)) flags |= R_TYPE_ERROR; }
+    };
+
+    double tmin;
+    auto read_next_decisions = [&]() {
+        double lmin = nd[0];
+#pragma unroll
+        for (int i = 1; i < NAC; i++) lmin = nanmin2(lmin, nd[i]);
+        tmin = wave_nanmin(lmin);
+    };
+    auto latest_arrival = [&]() {                                            // max(x) if x else 0 over the whole arrival lists
+        double lmax = amx[0];
+#pragma unroll
+        for (int i = 1; i < NAC; i++) lmax = amx[i] > lmax ? amx[i] : lmax;
+        return wave_nanmax(lmax);
+    };
+    read_next_decisions();
+    double vis_lo = __builtin_inf(), vis_hi = -__builtin_inf();
+    constexpr uint32_t ALL_CHUNKS = (1u << NTL) - 1u;
+    while (!finished_flag && now < P.cutoff) {                               // :565
+        if (REACTIVE && !(now >= vis_lo && now < vis_hi)) {                  // :566-567 (once per visibility window)
+            const double q = py_floordiv(now, (double)P.vis_period);
+            vis_lo = q * (double)P.vis_period; vis_hi = (q + 1.0) * (double)P.vis_period;
+            double v = q * (double)P.vis_batch + (double)P.vis_initial;
+            v = v < (double)P.vis_initial ? (double)P.vis_initial : v; v = v > (double)P.vis_cap ? (double)P.vis_cap : v;
+            visible = (int)v;
+        }
+        // next_decision :283-289
+        const bool any = (tmin == tmin);
+        now = any ? tmin : latest_arrival();                                 // :569
+        uint64_t dm[NAC];                                                    // the deciding set (exact ==), fixed before the updates
+#pragma unroll
+        for (int i = 0; i < NAC; i++) dm[i] = __ballot(any && nd[i] == tmin);
+        task_update(ALL_CHUNKS);                                             // :570
+        agent_update();                                                      // :571
+        if (flags & R_TYPE_ERROR) break;
+        if (!any) { if (++guard > 8) { flags |= DCM_FLAG_TRUNCATED; break; } } else guard = 0;
+#pragma unroll
+        for (int i = 0; i < NAC; i++) {
+            uint64_t m = dm[i];
+            while (m) {                                                      // :572 for agent in decision_agents
+                const int l = __ffsll((unsigned long long)m) - 1, a = i * WAVE + l;
+                m &= m - 1;
+                // the action: the next entry of the preset route, or a forced depot visit (:573-585) -- evaluated by every lane
+                // for its own agent, lane l's result is the one that counts
+                const bool exhausted = len[i] < 0 || head[i] >= len[i];
+                const bool hidden = REACTIVE && nxt[i] > visible;
+                const bool pop_l = !exhausted && !hidden;
+                const int action = rli(pop_l ? nxt[i] : 0, l);
+                const bool popped = (__ballot(pop_l) >> l) & 1ull;
+                if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
+                const int k = action - 1, kl = k & 63, kc = k >= 0 ? (k >> 6) : -1;
+                // agent_step :300-324.  Target location from the task's lane; the distance chain on all lanes (each from its own
+                // position: fp64 VALU work with fewer than 16 active lanes is 4x slower on gfx950), lane l commits
+                double tx_ = depot_x, ty_ = depot_y;
+#pragma unroll
+                for (int c = 0; c < NTL; c++) { const double x = rl(tx[c], kl), y = rl(ty[c], kl); tx_ = c == kc ? x : tx_; ty_ = c == kc ? y : ty_; }
+                const double d = dist2(ax[i], ay[i], tx_, ty_);
+                const double arrival_l = now + over_velocity(d);             // :315,:318
+                const double arrival = rl(arrival_l, l);
+                const bool me = lane == l;
+                // the task's side: is the agent already listed?  (:321-322)
+                uint32_t kinfo = 0;
+                uint64_t kids = 0;
+#pragma unroll
+                for (int c = 0; c < NTL; c++) if (c == kc) { kinfo = (uint32_t)rli((int)ti[c], kl); kids = rl64(ids[c], kl); }
+                int n = (kinfo >> 16) & 0xFF, pos = -1;
+                bool fresh = false;
+                if (action) {
+                    IdW<1> w{{kids}};
+                    pos = w.find((uint32_t)a, n);
+                    if (pos < 0) {
+                        if (n >= MR) flags |= DCM_FLAG_OVERFLOW;
+                        else { pos = n++; fresh = true; }
+                    }
+                }
+                const bool joined = pos >= 0;
+                if (fresh) kids |= (uint64_t)(uint32_t)a << (8 * pos);
+#pragma unroll
+                for (int c = 0; c < NTL; c++) if (c == kc) {
+                    const bool mk = lane == kl;
+                    ids[c] = mk ? kids : ids[c];
+                    ti[c] = mk ? ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16)) : ti[c];
+#pragma unroll
+                    for (int j = 0; j < CMR; j++) sl[c][j] = (mk && j == pos) ? arrival : sl[c][j];
+                }
+                // the agent's side
+                td[i] = me ? td[i] + d : td[i];                              // :317
+                // a member released by its task finishing before it arrived re-decides early, so the list is not monotone in
+                // replays with surplus visitors; :286 takes the max over the whole list
+                amx[i] = (me && (cur[i] == -2 || arrival_l > amx[i])) ? arrival_l : amx[i];
+                arr[i] = me ? arrival_l : arr[i];
+                ax[i] = me ? tx_ : ax[i]; ay[i] = me ? ty_ : ay[i];          // :320
+                cur[i] = me ? k : cur[i];                                    // :314
+                ai[i] = me ? ((ai[i] & ~A_MEMBER) | (action == 0 ? A_INDEPOT : 0u) | (joined ? A_MEMBER : 0u)) : ai[i];
+                if (popped) {                                                // :585 pop(0): the cursor moves on, the next entry is staged
+                    const int h1 = head[i] + 1;
+                    const int own = i * WAVE + lane < A ? i * WAVE + lane : 0;      // (every lane for its own agent; lane l's counts)
+                    const int up = h1 < len[i] ? lroute[own * route_cap + (h1 < route_cap ? h1 : 0)] : 0;
+                    head[i] = me ? h1 : head[i];
+                    nxt[i] = me ? up : nxt[i];
+                }
+                if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
+                // :575/:582/:586 -- after a call that changed nothing that a second call at the same `now` could change again
+                // (redo false) every task but the joined one is at a fixed point of task_update: only its chunk is evaluated
+                const uint32_t cm = redo ? ALL_CHUNKS : (kc >= 0 ? (1u << kc) : 0u);
+                if (cm) task_update(cm); else if (n_infeas == 0) task_update(0u);
+                // the agent now stands at task k: cache its finish time if it is feasible
+                {
+                    double tfk = NaN;
+#pragma unroll
+                    for (int c = 0; c < NTL; c++) if (c == kc) { const bool fk = (uint32_t)rli((int)ti[c], kl) & T_FEAS; const double t2 = rl(tf[c], kl); tfk = fk ? t2 : NaN; }
+                    ctf[i] = me ? tfk : ctf[i];
+                }
+                agent_update();                                              // :576/:583/:587
+                if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
+            }
+            if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
+        }
+        if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
+        // check_finished :366-373,:588
+        read_next_decisions();
+        if (!(tmin == tmin)) {
+            now = latest_arrival();
+            bool allret = true, allfin = TL >= T;                            // (a task that is never live is never finished)
+#pragma unroll
+            for (int i = 0; i < NAC; i++) allret = allret && (i * WAVE + lane >= A || (ai[i] & A_RETURNED));
+#pragma unroll
+            for (int c = 0; c < NTL; c++) allfin = allfin && (c * WAVE + lane >= T || (ti[c] & T_FIN));
+            finished_flag = __all(allret) && __all(allfin);
+        } else finished_flag = false;
+    }
+    WSYNC();
+    // ---- outputs per task and get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
+    double* const tw = (double*)smem;                                        // f64[T]
+    double* const awl = tw + T;                                              // f64[A]
+    double* const tdl = awl + A;                                             // f64[A]
+#pragma nounroll
+    for (int t = NTL * WAVE + lane; t < T; t += WAVE) tw[t] = 0.0;           // tasks that were never live (exactly as loaded)
+    double mxr[NTL];
+    int nfin = 0;
+#pragma unroll
+    for (int c = 0; c < NTL; c++) {
+        const int t = c * WAVE + lane;
+        const uint32_t info = ti[c];
+        const int n = (info >> 16) & 0xFF;
+        const bool feas = info & T_FEAS;
+        double mx = sl[c][0];
+#pragma unroll
+        for (int j = 1; j < CMR; j++) mx = nanmax2(mx, sl[c][j]);
+        mxr[c] = mx;
+        double term[CMR];
+#pragma unroll
+        for (int j = 0; j < CMR; j++) term[j] = feas ? (mx - sl[c][j]) : (now - sl[c][j]);
+        double s = 0.0;
+        if (CMR == 8 && n == 8) s = ((term[0] + term[1 % CMR]) + (term[2 % CMR] + term[3 % CMR])) + ((term[4 % CMR] + term[5 % CMR]) + (term[6 % CMR] + term[7 % CMR]));
+        else {
+#pragma unroll
+            for (int j = 0; j < CMR; j++) s = j < n ? s + term[j] : s;
+        }
+        const double w = s + (double)nab[c] * mwt;
+        nfin += __popcll(__ballot(t < T && (info & T_FIN)));
+        if (t < T) {
+            tw[t] = w;
+            const size_t o = (size_t)e * T + t;
+            if (finished) finished[o] = (info & T_FIN) ? 1 : 0;
+            if (task_wait) task_wait[o] = w;
+            if (n_members) n_members[o] = n;
+            if (time_finish) time_finish[o] = tf[c];
+        }
+    }
+#pragma nounroll
+    for (int t = NTL * WAVE + lane; t < T; t += WAVE) {
+        const size_t o = (size_t)e * T + t;
+        if (finished) finished[o] = 0;
+        if (task_wait) task_wait[o] = 0.0;
+        if (n_members) n_members[o] = 0;
+        if (time_finish) time_finish[o] = 0.0;
+    }
+    // :358-364 per agent in the reference's order: tasks ascending, member term first, then +max_waiting_time per entry of the
+    // agent in that task's abandoned_agent list (entries from the abandonment log, sorted by task id).  Task-major: a
+    // wave-uniform walk over the tasks that list members, each listed agent's lane adds its term.
+    double aw[NAC];
+    int abp[NAC], abn[NAC];
+    bool over = false, any_ab = false;
+#pragma unroll
+    for (int i = 0; i < NAC; i++) {
+        aw[i] = 0.0; abp[i] = 0;
+        const uint32_t na = ai[i] >> 16;
+        abn[i] = na < (uint32_t)AB_CAP ? (int)na : AB_CAP;
+        over = over || na > (uint32_t)AB_CAP;
+        any_ab = any_ab || na != 0;
+        if (na > 1) {                                                        // sort the agent's log by task id (insertion sort)
+            uint16_t* my = gab + (i * WAVE + lane) * AB_CAP;
+            for (int q = 1; q < abn[i]; q++) {
+                const uint16_t v = my[q];
+                int j = q;
+                while (j > 0 && my[j - 1] > v) { my[j] = my[j - 1]; j--; }
+                my[j] = v;
+            }
+        }
+    }
+    const bool has_ab = __any(any_ab);
+    if (__any(over)) flags |= DCM_FLAG_WAIT_ORDER;
+#pragma unroll
+    for (int c = 0; c < NTL; c++) {
+        uint64_t tm = __ballot(((ti[c] >> 16) & 0xFF) != 0 || nab[c] != 0);
+        for (; tm; tm &= tm - 1) {
+            const int L = __ffsll((unsigned long long)tm) - 1, t = c * WAVE + L;
+            const uint32_t info = (uint32_t)rli((int)ti[c], L);
+            const uint64_t idw = rl64(ids[c], L);
+            const int n = (info >> 16) & 0xFF;
+            const bool feas = info & T_FEAS;
+            const double mx = rl(mxr[c], L);
+#pragma unroll
+            for (int j = 0; j < CMR; j++) if (j < n) {
+                const int id = (int)((idw >> (8 * j)) & 0xFFu);
+                const double v = rl(sl[c][j], L);
+                double term;
+                if (feas) term = mx - v;                                      // :360
+                else { const double w = now - v; term = w > 0.0 ? w : 0.0; }  // :362
+#pragma unroll
+                for (int i = 0; i < NAC; i++) aw[i] = (i == (id >> 6) && lane == (id & 63)) ? aw[i] + term : aw[i];
+            }
+            if (has_ab) {                                                    // :363-364
+#pragma unroll
+                for (int i = 0; i < NAC; i++) {
+                    const uint16_t* my = gab + (i * WAVE + lane) * AB_CAP;
+                    while (abp[i] < abn[i] && my[abp[i]] == (uint16_t)t) { aw[i] += mwt; abp[i]++; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NAC; i++) {
+        const int a = i * WAVE + lane;
+        const uint32_t na = ai[i] >> 16;
+        aw[i] += (double)(na - (uint32_t)abn[i]) * mwt;
+        if (a < A) {
+            awl[a] = aw[i]; tdl[a] = td[i];
+            const size_t o = (size_t)e * A + a;
+            if (agent_wait) agent_wait[o] = aw[i];
+            if (travel_dist) travel_dist[o] = td[i];
+            if (returned) returned[o] = (ai[i] & A_RETURNED) ? 1 : 0;
+        }
+    }
+    WSYNC();
+    const double Td = (double)T, Ad = (double)A;
+    const double m3 = psum<4>(awl, A) / Ad, m4 = psum<4>(tdl, A), m5 = psum<4>(tw, T) / Td;
+    WSYNC();
+    // np.nanmean(time_start) (worker.py:105): one serial pairwise sum over T values, through the bytes the waiting sums have left
+#pragma unroll
+    for (int c = 0; c < NTL; c++) {
+        const int t = c * WAVE + lane;
+        if (t < T) { tw[t] = ts[c]; if (time_start) time_start[(size_t)e * T + t] = ts[c]; }
+    }
+#pragma nounroll
+    for (int t = NTL * WAVE + lane; t < T; t += WAVE) { tw[t] = 0.0; if (time_start) time_start[(size_t)e * T + t] = 0.0; }
+    WSYNC();
+    const double m2 = psum<4>(tw, T) / Td;
+    if (lane == 0) {
+        double* row = summary + (size_t)e * 8;
+        row[0] = -now; row[1] = (double)nfin; row[2] = (double)nfin / Td; row[3] = now;
+        row[4] = m2; row[5] = m3; row[6] = m4; row[7] = m5;
+        if (steps_out) steps_out[e] = steps;
+        if (flags_out) flags_out[e] = flags | DCM_FLAG_DONE | (finished_flag ? DCM_FLAG_FINISHED : 0u);
+    }
+}

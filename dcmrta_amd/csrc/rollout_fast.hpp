@@ -299,9 +299,8 @@ struct Fast {
                 rest &= ~(1ull << f); rlen--;                                    // :332-333
                 mm |= 1ull << f;
                 mlist |= (uint64_t)(uint32_t)f << (8 * nm);
-                // v_writelane: lane f takes its list position
-                // (gfx9 allows one SGPR on the constant bus: the value goes there, the lane select through M0)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypos) : "s"(nm), "s"(f));   // (M0 is reserved: the compiler never keeps a value in it)
+                // lane f takes its list position
+                mypos = lane == f ? nm : mypos;
                 nm++;
             }
         }

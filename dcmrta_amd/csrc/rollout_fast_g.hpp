@@ -406,7 +406,7 @@ struct FastG {
                 for (int ac = 0; ac < NAC; ac++) if (ac == (f >> 6)) {
                     rest[ac] &= ~(1ull << fl);
                     mm[ac] |= 1ull << fl;
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypos[ac]) : "s"(nm), "s"(fl));
+                    mypos[ac] = lane == fl ? nm : mypos[ac];
                 }
                 nm++;
             }

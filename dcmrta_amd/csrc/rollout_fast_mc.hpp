@@ -376,7 +376,7 @@ struct FastM {
                 rest &= ~(1ull << f); rlen--;                                    // :332-333
                 mm |= 1ull << f;
                 mlist |= (uint64_t)(uint32_t)f << (8 * nm);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(mypos) : "s"(nm), "s"(f));
+                mypos = lane == f ? nm : mypos;
                 nm++;
             }
         }

@@ -6,6 +6,7 @@ episode returns so that every rank holds the full return vector -- the analogue 
 8 runner results (driver.py:129-130) and of the reward vectors fed to ttest_rel (driver.py:244-280).
 torch.distributed backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
 """
+import datetime
 import os
 from dataclasses import dataclass
 
@@ -55,7 +56,9 @@ class DistContext:
     backend: str = ""
 
     @classmethod
-    def from_env(cls, expected_world=None, backend=None, device=None):
+    def from_env(cls, expected_world=None, backend=None, device=None, timeout_s=None):
+        """timeout_s: limit of the process-group bring-up and of every collective (default: DCM_DIST_TIMEOUT, else 120 s) -- a rank
+        that hangs makes the others fail with a reason instead of holding the job until the caller's own limit."""
         # before anything initialises HIP/HSA: the host driver of this pool only supports dmabuf IPC (without it RCCL fails
         # with hipIpcGetMemHandle: invalid argument)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -70,6 +73,12 @@ class DistContext:
             # together with DCM_DIST_BACKEND=gloo; RCCL itself needs one device per rank)
             forced = os.environ.get("DCM_FORCE_DEVICE")
             idx = int(forced) if forced is not None else local
+            # preflight BEFORE any other GPU call (device_count does not initialise the GPU): one device per local rank
+            n_dev = torch.cuda.device_count()
+            if n_dev > 0 and idx >= n_dev:
+                raise RuntimeError(f"rank {rank} (local rank {local}) needs HIP device {idx} but this node shows {n_dev} device(s): "
+                                   f"--gpus / WORLD_SIZE {world} is larger than the device count (set DCM_FORCE_DEVICE=<ordinal> "
+                                   f"with DCM_DIST_BACKEND=gloo to share one GPU between ranks)")
             device = torch.device("cuda", idx) if torch.cuda.is_available() else torch.device("cpu")
         be = ""
         # DCM_DIST_FORCE_INIT=1: initialise the process group even for one rank (exercises the RCCL branch on a 1-GPU box)
@@ -80,7 +89,10 @@ class DistContext:
                 torch.cuda.set_device(device)
             if not dist.is_initialized():
                 kw = {"device_id": device} if (be == "nccl") else {}
-                dist.init_process_group(backend=be, rank=rank, world_size=world, **kw)
+                if timeout_s is None:
+                    timeout_s = float(os.environ.get("DCM_DIST_TIMEOUT", "120"))
+                dist.init_process_group(backend=be, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(timeout_s)),
+                                        **kw)
         return cls(rank, world, local, device, be)
 
     def _coll_device(self):
@@ -188,6 +200,18 @@ class DistContext:
     def group_size(self):
         """Rank count as the process group (RCCL / gloo) itself reports it; None without a group."""
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else None
+
+    def device_names(self):
+        """Per-rank device description gathered over the group (rank order): "cuda:<ordinal> <marketing name>" -- rank 0 prints
+        it next to process_group_ranks so that a line shows WHICH devices the N ranks really ran on."""
+        me = str(self.device)
+        if self.device.type == "cuda":
+            me += " " + torch.cuda.get_device_name(self.device)
+        if not self._active():
+            return [me]
+        names = [None] * dist.get_world_size()
+        dist.all_gather_object(names, me)
+        return names
 
     def shutdown(self):
         if self._active():

@@ -88,6 +88,11 @@ def lib():
         L.orc_pairwise_sum.argtypes = [vp, i64]
         L.orc_batch_rollout.restype = i64
         L.orc_batch_rollout.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_batch_rollout_ex.restype = i64
+        L.orc_batch_rollout_ex.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.orc_batch_replay.restype = i64
+        L.orc_batch_replay.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int,
+                                       vp, vp, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -189,7 +194,7 @@ class OracleEnv:
 
     # whole episodes ------------------------------------------------------------------------
     def rollout(self, seed_e, d0=0, policy=POLICY_RANDOM, cap_steps=4096, record=True,
-                inj_leader=None, inj_action=None, inj_nfol=None, inj_followers=None):
+                inj_leader=None, inj_action=None, inj_nfol=None, inj_followers=None, allow_cap=False):
         A, T = self.A, self.T
         n = int(cap_steps)
         rec = {}
@@ -204,7 +209,9 @@ class OracleEnv:
         steps = lib().orc_rollout(self._h, C.c_uint64(seed_e), C.c_uint64(d0), int(policy), n,
                                   *[_p(x) for x in inj], *[_p(rec.get(k)) for k in order])
         if steps < 0:
-            raise RuntimeError("oracle rollout exceeded cap_steps")
+            if not allow_cap:
+                raise RuntimeError("oracle rollout exceeded cap_steps")
+            steps = n        # the first cap_steps decisions were recorded; the episode is NOT over (no terminal results)
         out = {k: v[:steps] for k, v in rec.items()}
         out["n_steps"] = int(steps)
         out.update(self.final())
@@ -275,3 +282,40 @@ def batch_rollout(depot, task_xy, req, dur, seeds, A, episodes=1, threads=1):
     total = lib().orc_batch_rollout(B, int(A), T, _p(depot), _p(task_xy), _p(req), _p(dur), _p(seeds), int(episodes),
                                     int(threads), _p(reward), _p(steps), _p(metrics))
     return int(total), reward, steps, metrics
+
+
+def batch_rollout_full(depot, task_xy, req, dur, seeds, A, episodes=1, threads=1):
+    """batch_rollout plus every episode's return and the last episode's finished-task count: dict(total, reward[B], steps[B],
+    metrics[B,6], returns[B,episodes], n_finished[B]) -- what the full-batch parity checks compare the HIP path with."""
+    depot = np.ascontiguousarray(depot, np.float64)
+    task_xy = np.ascontiguousarray(task_xy, np.float64)
+    req = np.ascontiguousarray(req, np.int32)
+    dur = np.ascontiguousarray(dur, np.float64)
+    seeds = np.ascontiguousarray(seeds, np.uint64)
+    B, T = req.shape
+    reward, steps, metrics = np.zeros(B), np.zeros(B, np.int64), np.zeros((B, 6))
+    returns, nfin = np.zeros((B, int(episodes))), np.zeros(B, np.int32)
+    total = lib().orc_batch_rollout_ex(B, int(A), T, _p(depot), _p(task_xy), _p(req), _p(dur), _p(seeds), int(episodes),
+                                       int(threads), _p(reward), _p(steps), _p(metrics), _p(returns), _p(nfin))
+    return dict(total=int(total), reward=reward, steps=steps, metrics=metrics, returns=returns, n_finished=nfin)
+
+
+def batch_replay(depot, task_xy, req, dur, routes, route_len, reactive=False, visibility=None, threads=1):
+    """execute_by_route for a batch (routes int32[B,A,cap], route_len int32[B,A], -1 = None): dict(total, reward[B], steps[B]
+    = agent_step calls, metrics[B,6], n_finished[B], status[B]: 0 ok / 1 guard-truncated / 2 TypeError)."""
+    depot = np.ascontiguousarray(depot, np.float64)
+    task_xy = np.ascontiguousarray(task_xy, np.float64)
+    req = np.ascontiguousarray(req, np.int32)
+    dur = np.ascontiguousarray(dur, np.float64)
+    routes = np.ascontiguousarray(routes, np.int32)
+    route_len = np.ascontiguousarray(route_len, np.int32)
+    B, T = req.shape
+    A = route_len.shape[1]
+    assert routes.shape[:2] == (B, A)
+    vis = None if visibility is None else np.ascontiguousarray(visibility, np.int32)
+    reward, steps, metrics = np.zeros(B), np.zeros(B, np.int64), np.zeros((B, 6))
+    nfin, status = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    total = lib().orc_batch_replay(B, A, T, _p(depot), _p(task_xy), _p(req), _p(dur), _p(routes), _p(route_len),
+                                   int(routes.shape[2]), int(bool(reactive)), _p(vis), int(threads), _p(reward), _p(steps),
+                                   _p(metrics), _p(nfin), _p(status))
+    return dict(total=int(total), reward=reward, steps=steps, metrics=metrics, n_finished=nfin, status=status)

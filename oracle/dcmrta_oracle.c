@@ -677,6 +677,13 @@ typedef struct {
     const uint64_t *seeds;
     double *reward_out, *metrics_out;
     int64_t *steps_out;
+    double *returns_out;     /* [B, episodes]: every episode's reward (nullable) */
+    int32_t *n_finished_out; /* [B]: finished tasks of the last episode (nullable) */
+    /* route replay (routes != NULL): execute_by_route instead of the RL loop */
+    const int32_t *routes, *route_len;
+    int route_cap, reactive;
+    const int32_t *visibility; /* 4 ints or NULL */
+    int32_t *status_out;       /* [B]: 0 ok, 1 truncated, 2 TypeError (nullable) */
     int next; /* work counter */
     int64_t total;
     pthread_mutex_t mu;
@@ -684,44 +691,93 @@ typedef struct {
 
 static void *batch_worker(void *arg) {
     batch_job *j = (batch_job *)arg;
-    orc_env *e = orc_create(j->A, j->T);
+    orc_env *e = j->routes ? NULL : orc_create(j->A, j->T);
     int64_t local = 0;
     for (;;) {
         pthread_mutex_lock(&j->mu);
         int b = j->next < j->B ? j->next++ : -1;
         pthread_mutex_unlock(&j->mu);
         if (b < 0) break;
+        if (j->routes) e = orc_create(j->A, j->T); /* the preset lists are consumed by the replay: a fresh env each */
         orc_load_instance(e, j->depot + 2 * (size_t)b, j->task_xy + 2 * (size_t)b * j->T, j->req + (size_t)b * j->T, j->dur + (size_t)b * j->T);
-        uint64_t d = 0;
         int64_t steps = 0;
-        for (int ep = 0; ep < j->episodes; ep++) {
-            if (ep) orc_clear_decisions(e);
-            int64_t n = orc_rollout(e, j->seeds[b], d, ORC_POLICY_RANDOM, (int64_t)1 << 40, NULL, NULL, NULL, NULL,
-                                    NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
-            d += (uint64_t)n; steps += n;
+        int status = 0;
+        if (j->routes) {
+            if (j->visibility) orc_set_visibility(e, j->visibility[0], j->visibility[1], j->visibility[2], j->visibility[3]);
+            for (int a = 0; a < j->A; a++) {
+                int n = j->route_len[(size_t)b * j->A + a];
+                if (n >= 0) orc_pre_set_route(e, a, j->routes + ((size_t)b * j->A + a) * j->route_cap, n);
+            }
+            int rc = orc_execute_by_route(e, j->reactive);
+            if (rc == -2) status = 2;
+            orc_finish_episode(e);
+            for (int a = 0; a < j->A; a++) steps += e->route[a].n;       /* agent_step calls of the episode */
+            if (e->truncated && !status) status = 1;
+        } else {
+            uint64_t d = 0;
+            for (int ep = 0; ep < j->episodes; ep++) {
+                if (ep) orc_clear_decisions(e);
+                int64_t n = orc_rollout(e, j->seeds[b], d, ORC_POLICY_RANDOM, (int64_t)1 << 40, NULL, NULL, NULL, NULL,
+                                        NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+                d += (uint64_t)n; steps += n;
+                if (j->returns_out) { orc_summary s1; orc_summary_get(e, &s1); j->returns_out[(size_t)b * j->episodes + ep] = s1.reward; }
+            }
+            if (e->truncated) status = 1;
         }
         orc_summary s;
         orc_summary_get(e, &s);
         if (j->reward_out) j->reward_out[b] = s.reward;
         if (j->metrics_out) memcpy(j->metrics_out + 6 * (size_t)b, s.metrics, sizeof(double) * 6);
         if (j->steps_out) j->steps_out[b] = steps;
+        if (j->n_finished_out) j->n_finished_out[b] = s.n_finished;
+        if (j->status_out) j->status_out[b] = status;
         local += steps;
+        if (j->routes) { orc_destroy(e); e = NULL; }
     }
-    orc_destroy(e);
+    if (e) orc_destroy(e);
     pthread_mutex_lock(&j->mu);
     j->total += local;
     pthread_mutex_unlock(&j->mu);
     return NULL;
 }
 
+static int64_t batch_run(batch_job *j, int threads) {
+    pthread_mutex_init(&j->mu, NULL);
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, batch_worker, j);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    pthread_mutex_destroy(&j->mu);
+    return j->total;
+}
+
+int64_t orc_batch_rollout_ex(int B, int A, int T, const double *depot, const double *task_xy, const int32_t *req,
+                             const double *dur, const uint64_t *seeds, int episodes, int threads, double *reward_out,
+                             int64_t *steps_out, double *metrics_out, double *returns_out, int32_t *n_finished_out) {
+    batch_job j;
+    memset(&j, 0, sizeof j);
+    j.B = B; j.A = A; j.T = T; j.episodes = episodes; j.depot = depot; j.task_xy = task_xy; j.dur = dur; j.req = req; j.seeds = seeds;
+    j.reward_out = reward_out; j.metrics_out = metrics_out; j.steps_out = steps_out; j.returns_out = returns_out;
+    j.n_finished_out = n_finished_out;
+    return batch_run(&j, threads);
+}
+
 int64_t orc_batch_rollout(int B, int A, int T, const double *depot, const double *task_xy, const int32_t *req,
                           const double *dur, const uint64_t *seeds, int episodes, int threads, double *reward_out,
                           int64_t *steps_out, double *metrics_out) {
-    batch_job j = {B, A, T, episodes, depot, task_xy, dur, req, seeds, reward_out, metrics_out, steps_out, 0, 0, PTHREAD_MUTEX_INITIALIZER};
-    if (threads < 1) threads = 1;
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, batch_worker, &j);
-    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
-    free(th);
-    return j.total;
+    return orc_batch_rollout_ex(B, A, T, depot, task_xy, req, dur, seeds, episodes, threads, reward_out, steps_out, metrics_out, NULL, NULL);
+}
+
+int64_t orc_batch_replay(int B, int A, int T, const double *depot, const double *task_xy, const int32_t *req,
+                         const double *dur, const int32_t *routes, const int32_t *route_len, int route_cap, int reactive,
+                         const int32_t *visibility, int threads, double *reward_out, int64_t *steps_out, double *metrics_out,
+                         int32_t *n_finished_out, int32_t *status_out) {
+    batch_job j;
+    memset(&j, 0, sizeof j);
+    j.B = B; j.A = A; j.T = T; j.episodes = 1; j.depot = depot; j.task_xy = task_xy; j.dur = dur; j.req = req;
+    j.routes = routes; j.route_len = route_len; j.route_cap = route_cap; j.reactive = reactive; j.visibility = visibility;
+    j.reward_out = reward_out; j.metrics_out = metrics_out; j.steps_out = steps_out; j.n_finished_out = n_finished_out;
+    j.status_out = status_out;
+    return batch_run(&j, threads);
 }

@@ -111,6 +111,23 @@ int64_t orc_batch_rollout(int B, int A, int T, const double *depot /*[B,2]*/, co
                           const int32_t *req /*[B,T]*/, const double *dur /*[B,T]*/, const uint64_t *seeds /*[B]*/,
                           int episodes, int threads, double *reward_out /*[B] last episode*/,
                           int64_t *steps_out /*[B]*/, double *metrics_out /*[B,6] last episode*/);
+/* the same, plus every episode's reward (returns_out[B, episodes]) and the last episode's finished-task count: what the
+ * full-batch parity checks compare with dcm_set_return_log / dcm_summary (worker.py:87,103-108).  Any output may be NULL. */
+int64_t orc_batch_rollout_ex(int B, int A, int T, const double *depot, const double *task_xy, const int32_t *req,
+                             const double *dur, const uint64_t *seeds, int episodes, int threads, double *reward_out,
+                             int64_t *steps_out, double *metrics_out, double *returns_out, int32_t *n_finished_out);
+
+/*
+ * Batch form of pre_set_route + execute_by_route + get_episode_reward (env/task_env.py:562-599, :420-425): B independent
+ * envs on `threads` pthreads.  routes[B,A,route_cap] actions, route_len[B,A] (-1 = pre_set_route stays None);
+ * visibility = the four schedule constants (NULL = the reference's).  steps_out[b] = agent_step calls of env b;
+ * status_out[b] = 0 ok, 1 ended by the zero-decider / step guard, 2 the reference raises TypeError (:220).
+ * Returns the total number of agent_step calls.
+ */
+int64_t orc_batch_replay(int B, int A, int T, const double *depot, const double *task_xy, const int32_t *req,
+                         const double *dur, const int32_t *routes, const int32_t *route_len, int route_cap, int reactive,
+                         const int32_t *visibility, int threads, double *reward_out, int64_t *steps_out,
+                         double *metrics_out /*[B,6]*/, int32_t *n_finished_out, int32_t *status_out);
 
 #ifdef __cplusplus
 }

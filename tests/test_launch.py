@@ -26,7 +26,10 @@ def test_requested_ranks_and_rank_environment():
     assert not launch.in_rank_environment({"PATH": "/bin"})
     cmd = launch.launcher_command("/x/bench.py", ["--gpus", "2", "--steps", "1"], 2, port=1234)
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
-    assert cmd[-5:] == ["/x/bench.py", "--gpus", "2", "--steps", "1"] and "127.0.0.1" in cmd
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "2", "--steps", "1"] and "127.0.0.1" in cmd and "1234" in cmd
+    # default: the launcher picks and holds its own rendezvous port (no probe-then-bind race between concurrent jobs)
+    cmd = launch.launcher_command("/x/bench.py", ["--gpus", "2"], 2)
+    assert "--standalone" in cmd and "--master-port" not in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
 
 
 def test_launch_module_imports_no_torch():
@@ -42,7 +45,7 @@ def test_plain_command_starts_its_own_ranks(n):
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == n and j["process_group_ranks"] == n and j["envs"] == 13 and j["self_launched"] == str(n)
-    assert j["gathered"] == [float(i) for i in range(13)]
+    assert j["gathered"] == [float(i) for i in range(13)] and j["rank_devices"] == ["cpu"] * n
 
 
 def test_failing_rank_propagates_exit_code():
@@ -65,3 +68,59 @@ def test_bench_self_launch_happens_before_heavy_imports():
     """bench.py's launcher call sits above its torch / HIP-library imports."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index("maybe_self_launch(__file__)") < src.index("import torch") < src.index("from dcmrta_amd import _lib")
+
+
+def test_hung_rank_ends_the_job_within_the_limit():
+    """A rank that never joins the process group: the others fail in bring-up after --dist-timeout with a reason, and if even
+    that does not end the job the parent's --launch-timeout ends the child tree it started: non-zero exit, no JSON line, nothing
+    left running."""
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, CHILD, "--gpus", "2", "--hang-rank", "1", "--dist-timeout", "600", "--launch-timeout", "25"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    took = time.monotonic() - t0
+    assert out.returncode == 124 and took < 90, (out.returncode, took, out.stderr[-2000:])
+    assert "did not finish within --launch-timeout" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # the ranks are gone (their command line carried the marker flag)
+    time.sleep(1.0)
+    left = []
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                cmd = open(f"/proc/{d}/cmdline").read()
+            except OSError:
+                continue
+            if "--hang-rank" in cmd and "launch_child.py" in cmd and "pytest" not in cmd:
+                left.append(d)
+    assert not left, left
+
+
+def test_hung_rank_fails_the_others_after_the_dist_timeout():
+    """--dist-timeout bounds process-group bring-up: the healthy rank gives up with an error, torch.distributed.run tears the job
+    down, the parent exits non-zero well before --launch-timeout."""
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, CHILD, "--gpus", "2", "--hang-rank", "1", "--dist-timeout", "8", "--launch-timeout", "240"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=400, cwd=ROOT)
+    took = time.monotonic() - t0
+    assert out.returncode not in (0, 124) and took < 200, (out.returncode, took, out.stderr[-2000:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_more_ranks_than_devices_is_a_clean_error(monkeypatch):
+    """WORLD_SIZE larger than the device count: the preflight (before any other GPU call) raises with a clear message."""
+    import torch
+    from dcmrta_amd.dist import DistContext
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    for k, v in dict(RANK="3", WORLD_SIZE="4", LOCAL_RANK="3").items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("DCM_FORCE_DEVICE", raising=False)
+    with pytest.raises(RuntimeError, match="larger than the device count"):
+        DistContext.from_env(expected_world=4)
+    # sharing one device on purpose is still possible
+    monkeypatch.setenv("DCM_FORCE_DEVICE", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    ctx = DistContext.from_env(expected_world=1)
+    assert ctx.world == 1
