@@ -326,14 +326,18 @@ struct Rep {
     static constexpr int AU_ONE = 0, AU_TASK = 1, AU_FULL = 2;
     // :221-222: when a depot agent whose next preset task `next` is not visible yet decides again -- np.max([arrival at the depot,
     // (next - 1) // batch * period, now])
-    __device__ __forceinline__ static double rearm_time(int next, double arrv, double now, int vis_batch, int vis_period) {
+    // ((next - 1) // batch * period of :221 as a double)
+    __device__ __forceinline__ static double rearm_quantum(int next, int vis_batch, int vis_period) {
         // (next - 1) // batch for 0 <= next - 1 < 65536 and 2 <= batch < 65536 is one multiply-high by this constant
         const uint32_t magic = vis_batch >= 2 && vis_batch < 65536 ? 0xFFFFFFFFu / (uint32_t)vis_batch + 1u : 0u;
         const int x = next - 1;
         int q;                                                               // python floor division
         if (magic && x >= 0 && x < 65536) q = (int)__umulhi((uint32_t)x, magic);
         else { q = x / vis_batch; if (x % vis_batch != 0 && x < 0) q--; }
-        const double ndt = (double)(q * vis_period);
+        return (double)(q * vis_period);
+    }
+    __device__ __forceinline__ static double rearm_time(int next, double arrv, double now, int vis_batch, int vis_period) {
+        const double ndt = rearm_quantum(next, vis_batch, vis_period);
         double v = arrv;
         v = ndt > v ? ndt : v;
         v = now > v ? now : v;
@@ -824,8 +828,8 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
     // the general kernel, whose scratch block it places.
     {
         const int TL = reactive ? (env->T < env->vis[3] ? env->T : env->vis[3]) : env->T;
-        const uint32_t flds = replay_fast_lds_bytes(env->A, env->T, env->route_cap);
-        if (env->replay_placement == 0 && env->A <= 2 * WAVE && TL <= 2 * WAVE && env->member_cap <= 8 && flds <= 64u * 1024u) {
+        const uint32_t flds = replay_fast_lds_bytes(env->A, env->T, env->route_cap);   // (route_cap < 32768: the cursor and the length share a word)
+        if (env->replay_placement == 0 && env->A <= 2 * WAVE && TL <= 2 * WAVE && env->member_cap <= 8 && flds <= 64u * 1024u && env->route_cap < 32768) {
 #define REPLAYF(CMR, RE)                                                                                                     \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)k_replay_fast<2, 2, CMR, RE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds); \

@@ -7,10 +7,9 @@
 //     route cursor + next preset action, route[-1], flags, and a CACHE of its current task's time_finish (NaN while that task is
 //     not feasible) -- so agent_update (:207-243) is lane-local arithmetic on all agents at once: the literal reference
 //     semantics (every agent, every call) for the price the LDS version paid for one agent;
-//   * lane t of task chunk c owns LIVE task c*64 + t: status word, ordered member ids (one byte each), the member arrival slots
-//     (NaN-padded: v_min/v_max_f64 ignore them), time_start / time_finish, duration, location, len(abandoned_agent) -- so
-//     task_update (:245-281) is lane-local select code on a whole chunk at once; only the removal of members (rare) runs a
-//     wave-uniform loop;
+//   * lane t of task chunk c owns LIVE task c*64 + t: status word, time_finish and the member arrival slots (NaN-padded:
+//     v_min/v_max_f64 ignore them) -- so task_update (:245-281) is lane-local select code on a whole chunk at once; only the
+//     removal of members (rare) runs a wave-uniform loop;
 //   * what the agent_step of agent a on task k reads "by index" is v_readlane from the owning lanes; its results go back
 //     through lane-select moves.  No LDS access, no HBM access and no s_waitcnt on the loop's critical path except the
 //     2-byte LDS read of the agent's next route entry;
@@ -21,21 +20,43 @@
 //
 // Template: NAC agent chunks, NTL live task chunks, CMR member slots (bytes of one id word), REACTIVE = dynamic arrivals.
 // Sizes are runtime values (A <= 64 NAC, live tasks <= 64 NTL, member_cap <= CMR), so every replay of a small shape runs this
-// kernel too and the random parity sweeps exercise it.  LDS: the routes, int32[A][route_cap]; after the loop the same bytes
-// hold the terminal metrics' serial-sum inputs (f64[T] + 2 f64[A]).
+// kernel too and the random parity sweeps exercise it.
+//
+// Registers hold what every call of task_update / agent_update reads on every lane (54 VGPRs of state for <2,2,5>); what a step
+// reads or updates ONCE, by index, sits in LDS (FL below): the routes int32[A][route_cap], the live tasks' location / duration /
+// ordered member ids / len(abandoned_agent), the agents' travel_dist and max(arrival_time) (ds_add_f64 / ds_max_f64 by the
+// agent's own lane).  About 9 KB per env at 100A/500T; after the loop the head of the same bytes holds the terminal metrics'
+// serial-sum inputs (f64[T] + f64[A]).  time_start is written once per task to the handle's HBM scratch and read back at the end.
 
 __device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
-__host__ __device__ inline uint32_t replay_fast_lds_bytes(int A, int T, int route_cap) {
-    const uint32_t loop = (uint32_t)(4 * A * route_cap), term = (uint32_t)(8 * T + 16 * A);
-    return align16(loop > term ? loop : term);
+// LDS layout of k_replay_fast<NAC, NTL, ...>: [routes | txy | dur] are dead after the event loop and then hold tw f64[T], awl f64[A]
+struct FL {
+    int A, T, cap, NA, NT;                                                   // NA = 64 NAC agent lanes, NT = 64 NTL live-task lanes
+    __host__ __device__ uint32_t routes() const { return 0; }                                    // i32[A][cap]
+    __host__ __device__ uint32_t txy() const { return align16((uint32_t)(4 * A * cap)); }       // f64[NT][2]  task location
+    __host__ __device__ uint32_t dur() const { return txy() + 16u * (uint32_t)NT; }             // f64[NT]
+    __host__ __device__ uint32_t head_end() const { return dur() + 8u * (uint32_t)NT; }
+    __host__ __device__ uint32_t term_end() const { return align16((uint32_t)(8 * T + 8 * A)); }   // tw f64[T], awl f64[A]
+    __host__ __device__ uint32_t ids() const { return head_end() > term_end() ? head_end() : term_end(); }   // u64[NT]
+    __host__ __device__ uint32_t nab() const { return ids() + 8u * (uint32_t)NT; }              // u32[NT]
+    __host__ __device__ uint32_t td() const { return nab() + 4u * (uint32_t)NT; }               // f64[NA] travel_dist
+    __host__ __device__ uint32_t amx() const { return td() + 8u * (uint32_t)NA; }               // f64[NA] max(arrival_time)
+    __host__ __device__ uint32_t bytes() const { return align16(amx() + 8u * (uint32_t)NA); }
+};
+__host__ __device__ inline uint32_t replay_fast_lds_bytes(int A, int T, int route_cap, int NAC = 2, int NTL = 2) {
+    return FL{A, T, route_cap, 64 * NAC, 64 * NTL}.bytes();
 }
 
+#ifndef DCM_REPLAY_WAVES
+#define DCM_REPLAY_WAVES 1      // minimum waves per SIMD asked of the compiler for k_replay_fast
+#endif
+
 template <int NAC, int NTL, int CMR, bool REACTIVE>
-__global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int PA, int PT, int MR, RP P, const unsigned char* state,
+__global__ __launch_bounds__(WAVE, DCM_REPLAY_WAVES) void k_replay_fast(int A, int T, int TL, int PA, int PT, int MR, RP P, const unsigned char* state,
                                                      const int32_t* routes, const int32_t* route_len, int route_cap,
                                                      double* summary, int64_t* steps_out, uint32_t* flags_out,
                                                      uint8_t* finished, double* time_start, double* time_finish,
@@ -45,42 +66,58 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
     const int e = blockIdx.x, lane = threadIdx.x;
     const Lay EL{PA, PT};                                      // layout dims of the handle's records (>= the batch dims)
     const unsigned char* rec = state + (size_t)e * EL.rec_bytes();
-    const double *gtx = (const double*)(rec + EL.tx()), *gty = (const double*)(rec + EL.ty()), *gtd = (const double*)(rec + EL.tdur());
-    const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
     uint16_t* const gab = (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort());   // abandonment log u16[A][AB_CAP]
+    double* const gts = (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw());            // time_start f64[T] (written once per task)
+    // (reads of what the wave stored earlier go past the CU's vector L1)
+    auto gload = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);
-    const int32_t* my_routes = routes + (size_t)e * A * route_cap;
-    int32_t* const lroute = (int32_t*)smem;
+    const FL F{A, T, route_cap, WAVE * NAC, WAVE * NTL};
+    int32_t* const lroute = (int32_t*)(smem + F.routes());
+    double* const ltxy = (double*)(smem + F.txy());
+    double* const ldur = (double*)(smem + F.dur());
+    uint64_t* const lids = (uint64_t*)(smem + F.ids());
+    uint32_t* const lnab = (uint32_t*)(smem + F.nab());
+    double* const ltd = (double*)(smem + F.td());
+    double* const lamx = (double*)(smem + F.amx());
     const double NaN = __builtin_nan("");
+    {
+        const int32_t* my_routes = routes + (size_t)e * A * route_cap;
 #pragma nounroll
-    for (int i = lane; i < A * route_cap; i += WAVE) lroute[i] = my_routes[i];
-
-    // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance, into registers
-    uint32_t ti[NTL], nab[NTL];
-    uint64_t ids[NTL];
-    double tf[NTL], ts[NTL], dur[NTL], tx[NTL], ty[NTL], sl[NTL][CMR];
-#pragma unroll
-    for (int c = 0; c < NTL; c++) {
-        const int t = c * WAVE + lane, tt = t < TL ? t : 0;
-        const uint32_t req = t < TL ? (gti[tt] & 0xFFu) : 1u;                // lanes beyond the live tasks: an inert task
-        ti[c] = req | (req << 8); nab[c] = 0; ids[c] = 0;
-        tf[c] = 0.0; ts[c] = 0.0; dur[c] = gtd[tt]; tx[c] = gtx[tt]; ty[c] = gty[tt];
-#pragma unroll
-        for (int j = 0; j < CMR; j++) sl[c][j] = NaN;
+        for (int i = lane; i < A * route_cap; i += WAVE) lroute[i] = my_routes[i];
     }
-    double ax[NAC], ay[NAC], arr[NAC], nd[NAC], td[NAC], amx[NAC], ctf[NAC];
-    int nxt[NAC], cur[NAC], head[NAC], len[NAC];
+    // ---- clear_decisions (env/task_env.py:129-140) from the loaded instance
+    uint32_t ti[NTL];
+    double tf[NTL], sl[NTL][CMR];
+    {
+        const double *gtx = (const double*)(rec + EL.tx()), *gty = (const double*)(rec + EL.ty()), *gtd = (const double*)(rec + EL.tdur());
+        const uint32_t* gti = (const uint32_t*)(rec + EL.tinfo());
+#pragma unroll
+        for (int c = 0; c < NTL; c++) {
+            const int t = c * WAVE + lane, tt = t < TL ? t : 0;
+            const uint32_t req = t < TL ? (gti[tt] & 0xFFu) : 1u;            // lanes beyond the live tasks: an inert task
+            ti[c] = req | (req << 8);
+            tf[c] = 0.0;
+            ltxy[2 * t] = gtx[tt]; ltxy[2 * t + 1] = gty[tt]; ldur[t] = gtd[tt];
+            lids[t] = 0; lnab[t] = 0;
+#pragma unroll
+            for (int j = 0; j < CMR; j++) sl[c][j] = NaN;
+        }
+    }
+    double ax[NAC], ay[NAC], arr[NAC], nd[NAC], ctf[NAC], rq[NAC];           // rq: (next preset action - 1) // batch * period (:221)
+    int nxt[NAC], cur[NAC], hl[NAC];                                         // hl = route cursor | len(pre_set_route) << 16 (-1 = None)
     uint32_t ai[NAC];
 #pragma unroll
     for (int i = 0; i < NAC; i++) {
         const int a = i * WAVE + lane, aa = a < A ? a : 0;
-        len[i] = a < A ? route_len[(size_t)e * A + aa] : -1;                  // pre_set_route :595-599 (-1 = None)
-        head[i] = 0;
-        nxt[i] = len[i] > 0 ? my_routes[(size_t)aa * route_cap] : 0;
-        ax[i] = depot_x; ay[i] = depot_y; arr[i] = 0.0; td[i] = 0.0; amx[i] = 0.0; ctf[i] = NaN;
+        const int len = a < A ? route_len[(size_t)e * A + aa] : -1;          // pre_set_route :595-599
+        hl[i] = len << 16;
+        nxt[i] = len > 0 ? routes[((size_t)e * A + aa) * route_cap] : 0;
+        rq[i] = REACTIVE ? Rep::rearm_quantum(nxt[i], P.vis_batch, P.vis_period) : 0.0;
+        ax[i] = depot_x; ay[i] = depot_y; arr[i] = 0.0; ctf[i] = NaN;
         nd[i] = a < A ? 0.0 : NaN;
         cur[i] = -2; ai[i] = 0;
+        ltd[a] = 0.0; lamx[a] = 0.0;
     }
     double now = 0.0;
     uint32_t flags = 0;
@@ -91,8 +128,10 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
     WSYNC();
 
     // ---- task_update (:245-281) of the live chunks `cm` (bit c), lane-local; returns through redo / n_infeas
+    bool tu_changed = false;          // the last task_update call made a task feasible or removed members (what other agents' next decisions read)
     auto task_update = [&](uint32_t cm) {
         bool touched = false;
+        tu_changed = false;
 #pragma unroll
         for (int c = 0; c < NTL; c++) if ((cm >> c) & 1u) {
             const uint32_t info = ti[c];
@@ -106,15 +145,17 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
             // members leave: the earliest arrival is <= max - mwt (:262) / has waited max_waiting_time (:269: now - v is the
             // largest for the earliest member, and the first such member of the scan is always removed)
             const bool rm = (full && !ok) || (!feas && status > 0 && (now - mn >= mwt));
-            const double tfin = mx + dur[c];
-            ts[c] = ok ? mx : ts[c]; tf[c] = ok ? tfin : tf[c];              // :256-258
             const uint32_t ninfo = feas ? (info | ((!fin && now >= tf[c]) ? T_FIN : 0u))                  // :273-274
                                         : ((info & (T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)n << 16) | (ok ? T_FEAS : 0u));
             ti[c] = rm ? info : ninfo;
-            // only a task that is already over changes again at this `now` (finished, :273)
-            touched = touched || (ok && now >= tfin);
             const uint64_t bm = __ballot(ok);
-            if (bm) {                                                        // became feasible (once per task)
+            if (bm) {                                                        // became feasible (once per task) :256-258
+                tu_changed = true;
+                const double tfin = mx + ldur[c * WAVE + lane];
+                tf[c] = ok ? tfin : tf[c];
+                if (ok) gts[c * WAVE + lane] = mx;
+                // only a task that is already over changes again at this `now` (finished, :273)
+                touched = touched || (ok && now >= tfin);
                 n_infeas -= __popcll(bm);
                 // the agents standing at such a task cache its finish time (see agent_update)
                 for (uint64_t m = bm; m; m &= m - 1) {
@@ -126,11 +167,11 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
             }
             uint64_t rmm = __ballot(rm);
             if (rmm) {                                                       // :262-265 / :268-271, one task at a time, wave-uniform
-                touched = true;
+                touched = true; tu_changed = true;
                 for (; rmm; rmm &= rmm - 1) {
                     const int L = __ffsll((unsigned long long)rmm) - 1, t = c * WAVE + L;
                     const uint32_t inf = (uint32_t)rli((int)ti[c], L);
-                    uint64_t idw = rl64(ids[c], L);
+                    uint64_t idw = uni(lids[t]);
                     const int rq = inf & 0xFF, nn = (inf >> 16) & 0xFF, st = rq - nn;
                     double sv[CMR];
 #pragma unroll
@@ -172,13 +213,13 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
                         left--;
                     }
                     const bool me = lane == L;
-                    ids[c] = me ? idw : ids[c];
 #pragma unroll
                     for (int j = 0; j < CMR; j++) sl[c][j] = me ? sv[j] : sl[c][j];
-                    nab[c] += me ? (uint32_t)(nn - left) : 0u;
+                    if (lane == 0) { lids[t] = idw; lnab[t] += (uint32_t)(nn - left); }
                     // (the status byte is the one computed BEFORE the removal: quirk Q3)
                     ti[c] = me ? ((inf & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(st & 0xFF) << 8) | ((uint32_t)left << 16)) : ti[c];
                 }
+                WSYNC();
             }
         }
         redo = __any(touched);
@@ -188,35 +229,38 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
         }
     };
     // ---- agent_update (:207-243, with the reactive depot branch :213-224) for every agent, lane-local
-    auto agent_update = [&]() {
-        bool allf_vis = false;
-        if constexpr (REACTIVE) {                                            // :214 all(feasible[:visible_length])
-            uint64_t inf = 0;
+    // (am: the agent chunks to recompute -- all of them is the literal reference; after an agent_step that changed nothing another
+    //  agent's branch reads, the stepping agent's chunk is enough: everybody else would store what it holds)
+    constexpr uint32_t ALL_AGENTS = (1u << NAC) - 1u;
+    // np.all(feasible[:visible_length]) (:214): changes when the visibility window moves on or a task becomes feasible
+    bool allf_vis = false;
+    auto recount_visible = [&]() {
+        uint64_t inf = 0;
 #pragma unroll
-            for (int c = 0; c < NTL; c++) inf |= __ballot(c * WAVE + lane < visible && c * WAVE + lane < T && !(ti[c] & T_FEAS));
-            allf_vis = inf == 0;
-        }
+        for (int c = 0; c < NTL; c++) inf |= __ballot(c * WAVE + lane < visible && c * WAVE + lane < T && !(ti[c] & T_FEAS));
+        allf_vis = inf == 0;
+    };
+    auto agent_update = [&](uint32_t am) {
         bool terr = false;
 #pragma unroll
-        for (int i = 0; i < NAC; i++) {
+        for (int i = 0; i < NAC; i++) if ((am >> i) & 1u) {
             const int c = cur[i];
-            double v;
-            uint32_t a2 = ai[i];
+            double v = NaN;                                                                    // :226
             if constexpr (REACTIVE) {
-                const bool waits = !allf_vis && !(len[i] >= 0 && head[i] >= len[i]);          // :215-218
-                terr = terr || (c == -1 && waits && len[i] < 0);                               // :220 TypeError in the reference
-                const bool rearm = c == -1 && waits && len[i] >= 0;
-                const double vr = Rep::rearm_time(nxt[i], arr[i], now, P.vis_batch, P.vis_period);   // :221-222
-                a2 = rearm ? (a2 & ~A_INDEPOT) : a2;                                           // :223-224 depot['members'].remove
+                const int len = hl[i] >> 16, head = hl[i] & 0xFFFF;
+                const bool waits = !allf_vis && !(len >= 0 && head >= len);                    // :215-218
+                terr = terr || (c == -1 && waits && len < 0);                                  // :220 TypeError in the reference
+                const bool rearm = c == -1 && waits && len >= 0;
+                double vr = arr[i];                                                            // :221-222 np.max([arrival, quantum, now])
+                vr = rq[i] > vr ? rq[i] : vr;
+                vr = now > vr ? now : vr;
+                ai[i] = rearm ? (ai[i] & ~A_INDEPOT) : ai[i];                                  // :223-224 depot['members'].remove
                 v = rearm ? vr : NaN;
-            } else {
-                v = NaN;                                                                       // :226
             }
             const bool member = (ctf[i] == ctf[i]) && (ai[i] & A_MEMBER);                      // :228-230
             const double vt = member ? ctf[i] : arr[i] + mwt;                                  // :231 / :235,:238
             v = c >= 0 ? vt : v;
             nd[i] = c == -2 ? nd[i] : v;                                                       // :209 (an agent that never moved)
-            ai[i] = a2;
         }
         if constexpr (REACTIVE) { if (__any(terr)) flags |= R_TYPE_ERROR; }
     };
@@ -229,9 +273,9 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
         tmin = wave_nanmin(lmin);
     };
     auto latest_arrival = [&]() {                                            // max(x) if x else 0 over the whole arrival lists
-        double lmax = amx[0];
+        double lmax = lamx[lane];
 #pragma unroll
-        for (int i = 1; i < NAC; i++) lmax = amx[i] > lmax ? amx[i] : lmax;
+        for (int i = 1; i < NAC; i++) { const double v = lamx[i * WAVE + lane]; lmax = v > lmax ? v : lmax; }
         return wave_nanmax(lmax);
     };
     read_next_decisions();
@@ -252,7 +296,8 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
 #pragma unroll
         for (int i = 0; i < NAC; i++) dm[i] = __ballot(any && nd[i] == tmin);
         task_update(ALL_CHUNKS);                                             // :570
-        agent_update();                                                      // :571
+        if constexpr (REACTIVE) recount_visible();
+        agent_update(ALL_AGENTS);                                            // :571
         if (flags & R_TYPE_ERROR) break;
         if (!any) { if (++guard > 8) { flags |= DCM_FLAG_TRUNCATED; break; } } else guard = 0;
 #pragma unroll
@@ -263,76 +308,90 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
                 m &= m - 1;
                 // the action: the next entry of the preset route, or a forced depot visit (:573-585) -- evaluated by every lane
                 // for its own agent, lane l's result is the one that counts
-                const bool exhausted = len[i] < 0 || head[i] >= len[i];
-                const bool hidden = REACTIVE && nxt[i] > visible;
-                const bool pop_l = !exhausted && !hidden;
+                const int len_l = hl[i] >> 16, head_l = hl[i] & 0xFFFF;
+                const bool pop_l = !(len_l < 0 || head_l >= len_l) && !(REACTIVE && nxt[i] > visible);
                 const int action = rli(pop_l ? nxt[i] : 0, l);
                 const bool popped = (__ballot(pop_l) >> l) & 1ull;
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
-                const int k = action - 1, kl = k & 63, kc = k >= 0 ? (k >> 6) : -1;
-                // agent_step :300-324.  Target location from the task's lane; the distance chain on all lanes (each from its own
-                // position: fp64 VALU work with fewer than 16 active lanes is 4x slower on gfx950), lane l commits
-                double tx_ = depot_x, ty_ = depot_y;
-#pragma unroll
-                for (int c = 0; c < NTL; c++) { const double x = rl(tx[c], kl), y = rl(ty[c], kl); tx_ = c == kc ? x : tx_; ty_ = c == kc ? y : ty_; }
+                const int k = action - 1, kk = k >= 0 ? k : 0, kl = kk & 63, kc = k >= 0 ? (k >> 6) : -1;
+                // agent_step :300-324.  One LDS round trip: the task's location and member ids (wave-uniform address).  The distance
+                // chain runs on all lanes (each from its own position: fp64 VALU work with fewer than 16 active lanes is 4x slower
+                // on gfx950), lane l commits
+                const double txk = ltxy[2 * kk], tyk = ltxy[2 * kk + 1];
+                uint64_t kids = lids[kk];
+                const double tx_ = action ? txk : depot_x, ty_ = action ? tyk : depot_y;
                 const double d = dist2(ax[i], ay[i], tx_, ty_);
                 const double arrival_l = now + over_velocity(d);             // :315,:318
                 const double arrival = rl(arrival_l, l);
                 const bool me = lane == l;
                 // the task's side: is the agent already listed?  (:321-322)
                 uint32_t kinfo = 0;
-                uint64_t kids = 0;
 #pragma unroll
-                for (int c = 0; c < NTL; c++) if (c == kc) { kinfo = (uint32_t)rli((int)ti[c], kl); kids = rl64(ids[c], kl); }
+                for (int c = 0; c < NTL; c++) if (c == kc) kinfo = (uint32_t)rli((int)ti[c], kl);
                 int n = (kinfo >> 16) & 0xFF, pos = -1;
                 bool fresh = false;
                 if (action) {
-                    IdW<1> w{{kids}};
-                    pos = w.find((uint32_t)a, n);
+                    kids = uni(kids);
+                    // lane j compares member byte j (the list holds an agent at most once)
+                    const uint64_t hit = __ballot(lane < n && (int)((kids >> (8 * (lane & 7))) & 0xFFu) == a);
+                    pos = hit ? __ffsll((unsigned long long)hit) - 1 : -1;
                     if (pos < 0) {
                         if (n >= MR) flags |= DCM_FLAG_OVERFLOW;
                         else { pos = n++; fresh = true; }
                     }
+                    if (fresh) lids[kk] = kids | ((uint64_t)(uint32_t)a << (8 * pos));
                 }
                 const bool joined = pos >= 0;
-                if (fresh) kids |= (uint64_t)(uint32_t)a << (8 * pos);
+                // the task's word as task_update would leave it if the join changes nothing else: len(members), and for a task that
+                // is not feasible its status = requirements - len(members) (:250-252)
+                const bool feas_k = kinfo & T_FEAS;
+                const int status_k = (int)(kinfo & 0xFFu) - n;
+                const uint32_t kinfo2 = feas_k ? ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16))
+                                               : ((kinfo & (T_FIN | 0xFFu)) | ((uint32_t)(status_k & 0xFF) << 8) | ((uint32_t)n << 16));
 #pragma unroll
                 for (int c = 0; c < NTL; c++) if (c == kc) {
                     const bool mk = lane == kl;
-                    ids[c] = mk ? kids : ids[c];
-                    ti[c] = mk ? ((kinfo & ~0x00FF0000u) | ((uint32_t)n << 16)) : ti[c];
+                    ti[c] = mk ? kinfo2 : ti[c];
 #pragma unroll
                     for (int j = 0; j < CMR; j++) sl[c][j] = (mk && j == pos) ? arrival : sl[c][j];
                 }
-                // the agent's side
-                td[i] = me ? td[i] + d : td[i];                              // :317
-                // a member released by its task finishing before it arrived re-decides early, so the list is not monotone in
-                // replays with surplus visitors; :286 takes the max over the whole list
-                amx[i] = (me && (cur[i] == -2 || arrival_l > amx[i])) ? arrival_l : amx[i];
+                // the agent's side: travel_dist += d (:317) and max(arrival_time) by the agent's own lane in LDS (the others add 0 /
+                // offer 0: a member released by its task finishing before it arrived re-decides early, so the arrival list is not
+                // monotone in replays with surplus visitors; :286 takes the max over the whole list)
+                __hip_atomic_fetch_add(&ltd[i * WAVE + lane], me ? d : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                {
+                    const double mxv = lamx[i * WAVE + lane];
+                    lamx[i * WAVE + lane] = (me && arrival_l > mxv) ? arrival_l : mxv;
+                }
                 arr[i] = me ? arrival_l : arr[i];
                 ax[i] = me ? tx_ : ax[i]; ay[i] = me ? ty_ : ay[i];          // :320
                 cur[i] = me ? k : cur[i];                                    // :314
                 ai[i] = me ? ((ai[i] & ~A_MEMBER) | (action == 0 ? A_INDEPOT : 0u) | (joined ? A_MEMBER : 0u)) : ai[i];
                 if (popped) {                                                // :585 pop(0): the cursor moves on, the next entry is staged
-                    const int h1 = head[i] + 1;
                     const int own = i * WAVE + lane < A ? i * WAVE + lane : 0;      // (every lane for its own agent; lane l's counts)
-                    const int up = h1 < len[i] ? lroute[own * route_cap + (h1 < route_cap ? h1 : 0)] : 0;
-                    head[i] = me ? h1 : head[i];
+                    const int h1 = head_l + 1;
+                    const int up = h1 < len_l ? lroute[own * route_cap + (h1 < route_cap ? h1 : 0)] : 0;
+                    hl[i] = me ? hl[i] + 1 : hl[i];
                     nxt[i] = me ? up : nxt[i];
+                    if constexpr (REACTIVE) { const double q = Rep::rearm_quantum(up, P.vis_batch, P.vis_period); rq[i] = me ? q : rq[i]; }
                 }
                 if (++steps > step_cap) flags |= DCM_FLAG_TRUNCATED | DCM_FLAG_OVERFLOW;
-                // :575/:582/:586 -- after a call that changed nothing that a second call at the same `now` could change again
-                // (redo false) every task but the joined one is at a fixed point of task_update: only its chunk is evaluated
-                const uint32_t cm = redo ? ALL_CHUNKS : (kc >= 0 ? (1u << kc) : 0u);
-                if (cm) task_update(cm); else if (n_infeas == 0) task_update(0u);
+                // :575/:582/:586.  After a call that changed nothing a second call at the same `now` could change again (redo false)
+                // every task but the joined one is at a fixed point of task_update, and so is the joined one unless this join
+                // completes its coalition: a member who has just arrived has not waited (:269), a task that still lacks members
+                // only gets the status written above (:252-254), a feasible one was checked against this `now` already (:273).
+                const bool was_redo = redo;
+                const bool completes = action && !feas_k && status_k <= 0;
+                task_update(redo ? ALL_CHUNKS : (completes ? (1u << kc) : 0u));
                 // the agent now stands at task k: cache its finish time if it is feasible
-                {
+                if (action) {
                     double tfk = NaN;
 #pragma unroll
                     for (int c = 0; c < NTL; c++) if (c == kc) { const bool fk = (uint32_t)rli((int)ti[c], kl) & T_FEAS; const double t2 = rl(tf[c], kl); tfk = fk ? t2 : NaN; }
                     ctf[i] = me ? tfk : ctf[i];
                 }
-                agent_update();                                              // :576/:583/:587
+                if constexpr (REACTIVE) { if (tu_changed) recount_visible(); }
+                agent_update((was_redo || tu_changed) ? ALL_AGENTS : (1u << i));      // :576/:583/:587
                 if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
             }
             if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
@@ -354,10 +413,9 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
     // ---- outputs per task and get_episode_reward: calculate_waiting_time :344-364 (np.sum = pairwise block for n >= 8)
     double* const tw = (double*)smem;                                        // f64[T]
     double* const awl = tw + T;                                              // f64[A]
-    double* const tdl = awl + A;                                             // f64[A]
 #pragma nounroll
     for (int t = NTL * WAVE + lane; t < T; t += WAVE) tw[t] = 0.0;           // tasks that were never live (exactly as loaded)
-    double mxr[NTL];
+    double mxr[NTL], tsr[NTL];
     int nfin = 0;
 #pragma unroll
     for (int c = 0; c < NTL; c++) {
@@ -365,6 +423,7 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
         const uint32_t info = ti[c];
         const int n = (info >> 16) & 0xFF;
         const bool feas = info & T_FEAS;
+        tsr[c] = (feas && t < T) ? gload(&gts[t]) : 0.0;
         double mx = sl[c][0];
 #pragma unroll
         for (int j = 1; j < CMR; j++) mx = nanmax2(mx, sl[c][j]);
@@ -378,7 +437,7 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
 #pragma unroll
             for (int j = 0; j < CMR; j++) s = j < n ? s + term[j] : s;
         }
-        const double w = s + (double)nab[c] * mwt;
+        const double w = s + (double)lnab[t] * mwt;
         nfin += __popcll(__ballot(t < T && (info & T_FIN)));
         if (t < T) {
             tw[t] = w;
@@ -424,20 +483,20 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
     if (__any(over)) flags |= DCM_FLAG_WAIT_ORDER;
 #pragma unroll
     for (int c = 0; c < NTL; c++) {
-        uint64_t tm = __ballot(((ti[c] >> 16) & 0xFF) != 0 || nab[c] != 0);
+        uint64_t tm = __ballot(((ti[c] >> 16) & 0xFF) != 0 || lnab[c * WAVE + lane] != 0);
         for (; tm; tm &= tm - 1) {
             const int L = __ffsll((unsigned long long)tm) - 1, t = c * WAVE + L;
             const uint32_t info = (uint32_t)rli((int)ti[c], L);
-            const uint64_t idw = rl64(ids[c], L);
+            const uint64_t idw = uni(lids[t]);
             const int n = (info >> 16) & 0xFF;
             const bool feas = info & T_FEAS;
-            const double mx = rl(mxr[c], L);
+            const double mxt = rl(mxr[c], L);
 #pragma unroll
             for (int j = 0; j < CMR; j++) if (j < n) {
                 const int id = (int)((idw >> (8 * j)) & 0xFFu);
                 const double v = rl(sl[c][j], L);
                 double term;
-                if (feas) term = mx - v;                                      // :360
+                if (feas) term = mxt - v;                                     // :360
                 else { const double w = now - v; term = w > 0.0 ? w : 0.0; }  // :362
 #pragma unroll
                 for (int i = 0; i < NAC; i++) aw[i] = (i == (id >> 6) && lane == (id & 63)) ? aw[i] + term : aw[i];
@@ -457,22 +516,22 @@ __global__ __launch_bounds__(WAVE) void k_replay_fast(int A, int T, int TL, int 
         const uint32_t na = ai[i] >> 16;
         aw[i] += (double)(na - (uint32_t)abn[i]) * mwt;
         if (a < A) {
-            awl[a] = aw[i]; tdl[a] = td[i];
+            awl[a] = aw[i];
             const size_t o = (size_t)e * A + a;
             if (agent_wait) agent_wait[o] = aw[i];
-            if (travel_dist) travel_dist[o] = td[i];
+            if (travel_dist) travel_dist[o] = ltd[a];
             if (returned) returned[o] = (ai[i] & A_RETURNED) ? 1 : 0;
         }
     }
     WSYNC();
     const double Td = (double)T, Ad = (double)A;
-    const double m3 = psum<4>(awl, A) / Ad, m4 = psum<4>(tdl, A), m5 = psum<4>(tw, T) / Td;
+    const double m3 = psum<4>(awl, A) / Ad, m4 = psum<4>(ltd, A), m5 = psum<4>(tw, T) / Td;
     WSYNC();
     // np.nanmean(time_start) (worker.py:105): one serial pairwise sum over T values, through the bytes the waiting sums have left
 #pragma unroll
     for (int c = 0; c < NTL; c++) {
         const int t = c * WAVE + lane;
-        if (t < T) { tw[t] = ts[c]; if (time_start) time_start[(size_t)e * T + t] = ts[c]; }
+        if (t < T) { tw[t] = tsr[c]; if (time_start) time_start[(size_t)e * T + t] = tsr[c]; }
     }
 #pragma nounroll
     for (int t = NTL * WAVE + lane; t < T; t += WAVE) { tw[t] = 0.0; if (time_start) time_start[(size_t)e * T + t] = 0.0; }

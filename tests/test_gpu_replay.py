@@ -62,7 +62,10 @@ from dcmrta_amd.instances import synthetic_routes  # noqa: E402
                                               (13, 37, False, 8),
                                               # bench.py --config 5's setting: 5 member slots
                                               (100, 500, False, 5), (100, 500, True, 5)])
-@pytest.mark.parametrize("placement", ["lds", "hbm"])   # where the kernel keeps its replay scratch (auto: by batch size)
+# "auto": the register-resident kernel (replay_fast.hpp) when the live tasks fit two lane chunks -- 13A/37T, and every reactive case
+# at the reference's visibility cap of 100 -- else the general kernel with its own choice; "lds" / "hbm": the general kernel with
+# its replay scratch there
+@pytest.mark.parametrize("placement", ["auto", "lds", "hbm"])
 def test_replay_matches_oracle(gpu_device, oracle_lib, A, T, reactive, cap, placement):
     from dcmrta_amd.batched_env import BatchedTaskEnv
     from dcmrta_amd.instances import generate_batch
@@ -114,6 +117,37 @@ def test_random_route_replays_known_answers(gpu_device, golden_dir):
             n_ok += 1
         env.close()
     assert n_ok >= 15
+
+
+@pytest.mark.parametrize("cap", [8, 5])
+def test_random_route_replays_on_the_register_resident_kernel(gpu_device, golden_dir, cap):
+    """The same reference known answers through replay_fast.hpp (member_cap <= 8 and the default placement select it for these
+    shapes); cases in which a task collects more members than the slots hold are flagged DCM_FLAG_OVERFLOW and not compared."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from test_oracle_golden import random_replay_cases
+    n_ok = n_over = 0
+    for c, inst in random_replay_cases(golden_dir):
+        env = BatchedTaskEnv(1, c["A"], c["T"], device=gpu_device)
+        env.load_instances(inst["depot"][None], inst["task_xy"][None], inst["req"][None], inst["dur"][None])
+        env.load_routes([c["routes"]], member_cap=cap)
+        out = env.execute_routes(reactive=c["reactive"])
+        flags = int(out["flags"].cpu().numpy()[0])
+        name = (c["A"], c["T"], c["reactive"], cap)
+        if flags & 16:
+            n_over += 1
+        elif c["status"] == "type_error":
+            assert flags & 64, name
+        elif c["status"] == "no_termination":
+            assert flags & 4 and not flags & 64, name
+        else:
+            assert not flags & (4 | 64), name
+            for k in KEYS_EXACT:
+                exp = np.asarray(c["result"][k])
+                assert np.array_equal(out[k][0].cpu().numpy().astype(exp.dtype), exp), (name, k)
+            assert np.array_equal(out["summary"][0].cpu().numpy()[2:8], np.asarray(c["result"]["metrics"])), name
+            n_ok += 1
+        env.close()
+    assert n_ok >= (10 if cap == 8 else 5), (n_ok, n_over)
 
 
 def test_generalised_visibility_schedule(gpu_device, golden_dir, oracle_lib):

@@ -13,6 +13,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
           ["SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_BRANCH", "SQ_WAVES"]]
+if os.environ.get("REPLAY_PMC_CLASSES"):      # the VALU instruction classes as well (two more passes)
+    GROUPS += [["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_CVT",
+                "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"],
+               ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"]]
 out = {}
 for gi, grp in enumerate(GROUPS):
     d = f"/tmp/replay_pmc_{gi}"
