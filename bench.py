@@ -60,7 +60,7 @@ from dcmrta_amd.choice import env_seeds  # noqa: E402
 from dcmrta_amd.dist import DistContext, shard_range  # noqa: E402
 from dcmrta_amd.instances import generate_batch, synthetic_route_arrays  # noqa: E402
 from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step, issue_roofline, load_counters,  # noqa: E402
-                                 rollout_kernel_name, staleness, step_kernel_name)
+                                 replay_kernel_name, rollout_kernel_name, staleness, step_kernel_name)
 
 REFERENCE_VISIBILITY = (20, 20, 10, 100)      # env/task_env.py:567, :221
 CONFIGS = {
@@ -328,7 +328,8 @@ def other_config_shards(dev, visibility, passes=4):
     mid = dict(CONFIGS["2"], agents=70, tasks=130, episodes=3)     # a mid-size shape (env/task_env.py:57-65 draws sizes from ranges)
     for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
         A, T = cfg["agents"], cfg["tasks"]
-        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else cfg["kernel"], episodes=eps)
+        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else replay_kernel_name(A, T, 5, True, visibility[3]),
+                 episodes=eps)
         sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)
         sb.run(eps, True)
         torch.cuda.synchronize(dev)
@@ -361,7 +362,7 @@ class SubBatch:
 
     def __init__(self, cfg, first, B, dev, stream, visibility, reactive=True):
         A, T = cfg["agents"], cfg["tasks"]
-        self.first, self.B, self.stream, self.replay, self.reactive = first, B, stream, cfg["kernel"] == "k_replay", reactive
+        self.first, self.B, self.stream, self.replay, self.reactive = first, B, stream, cfg["kernel"].startswith("k_replay"), reactive
         self.inst = generate_batch(B, A, T, base_seed=0, first=first)
         self.seeds = env_seeds(0, first, B)
         self.env = BatchedTaskEnv(B, A, T, device=str(dev))
@@ -423,6 +424,7 @@ def main():
     visibility = (REFERENCE_VISIBILITY if (static_replay or not args.visibility) else tuple(int(x) for x in args.visibility.split(",")))
     if replay:
         EP = 1
+        cfg["kernel"] = replay_kernel_name(A, T, 5, not static_replay, visibility[3])     # (5 member slots: see SubBatch)
 
     ctx = DistContext.from_env(expected_world=args.gpus, timeout_s=args.dist_timeout)
     device_names = ctx.device_names()

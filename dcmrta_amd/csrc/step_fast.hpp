@@ -11,9 +11,12 @@
 // which nobody can decide, the end of an episode, auto-reset) takes the general code on the same LDS image, exactly as k_step.
 // The observation of the next decision is built from the registers when they hold the env, from the LDS image otherwise.
 #pragma once
+#ifndef DCM_STEP_WAVES
+#define DCM_STEP_WAVES 4       // minimum waves per SIMD asked of the compiler for k_step_fast
+#endif
 
 template <int CA, int CT, bool RS>
-__global__ __launch_bounds__(WAVE, 4) void k_step_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
+__global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
                                                    float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
                                                    uint8_t* active_out, double* summary, uint16_t* ablog, uint32_t mode,
                                                    const int32_t* sizes, unsigned char* gscr, uint32_t max_episodes, double* retlog,

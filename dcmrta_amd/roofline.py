@@ -116,6 +116,13 @@ def rollout_kernel_name(A, T):
     return "k_rollout_random"
 
 
+def replay_kernel_name(A, T, member_cap, reactive, vis_cap):
+    """Which kernel dcm_execute_routes launches (default placement): the register-resident one when the agents, the LIVE tasks (all
+    of them without dynamic arrivals, tasks 1..cap with them) and the member slots fit it, the general one otherwise."""
+    live = min(T, vis_cap) if reactive else T
+    return "k_replay_fast" if (A <= 128 and live <= 128 and member_cap <= 8) else "k_replay"
+
+
 def step_kernel_name(A, T):
     """The lockstep kernel dcm_step launches for the plain call shape (no injected choices, no route log, all outputs)."""
     return "k_step_fast" if (A <= 64 and T <= 63) else "k_step"

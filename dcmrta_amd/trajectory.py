@@ -43,53 +43,75 @@ def write_results_csv(path, summary):
             w.writerow([i] + [repr(float(x)) for x in r[2:8]])
 
 
+def _leg_table(aid, route, arrival, depot, task_xy, members, feasible, time_start, time_finish, mwt, velocity):
+    """One row per route entry of an agent: where the leg starts / ends, its heading, when the agent left the previous stop
+    (`leave`), when it reaches this one (`reach`) and until when it stays (`stay`) -- the quantities env/task_env.py:380-404 derive
+    from the final task state."""
+    n = len(route)
+    stop = np.asarray(route, np.int64)
+    xy = np.where((stop >= 0)[:, None], np.asarray(task_xy, np.float64)[np.maximum(stop, 0)], np.asarray(depot, np.float64)[None, :])
+    # the stop before entry i; the first leg, and any leg after a depot visit, starts at the depot with "previous decision" 0 (:387,:396)
+    before = np.concatenate([[-1], stop[:-1]])
+    src = np.where((before >= 0)[:, None], np.asarray(task_xy, np.float64)[np.maximum(before, 0)], np.asarray(depot, np.float64)[None, :])
+    reach = np.asarray(arrival, np.float64)
+    reach_before = np.concatenate([[0.0], reach[:-1]])
+    listed = np.array([s >= 0 and aid in members[s] for s in stop], bool)
+    listed_before = np.array([s >= 0 and aid in members[s] for s in before], bool)
+    feas = np.asarray(feasible, bool)
+    ts, tf = np.asarray(time_start, np.float64), np.asarray(time_finish, np.float64)
+    k, kb = np.maximum(stop, 0), np.maximum(before, 0)
+    works = listed & feas[k] & (stop >= 0)                                                  # :388
+    stay = np.where(works & (ts[k] - reach <= mwt), tf[k], reach + mwt)                     # :389-395
+    worked_before = listed_before & feas[kb] & (ts[kb] - reach_before <= mwt)               # :399
+    leave = np.where(before < 0, 0.0, np.where(worked_before, tf[kb], reach_before + mwt))  # :396-404
+    heading = np.arctan2(xy[:, 1] - src[:, 1], xy[:, 0] - src[:, 0])                        # :382-383
+    duration = np.array([np.linalg.norm(src[i] - xy[i]) for i in range(n)], np.float64) / velocity   # :384-385
+    return src, xy, heading, duration, leave, reach, stay
+
+
 def trajectories(routes, depot, task_xy, members, feasible, time_start, time_finish, current_time, max_waiting_time=10.0,
                  dt=0.1, velocity=0.2):
-    """generate_traj (env/task_env.py:375-418) as a pure function of an episode's final state.
+    """generate_traj (env/task_env.py:375-418) as a pure function of an episode's final state, bit-equal with the reference.
 
     routes: per agent (route, arrival_time) with task ids, -1 = depot; members: per task the final member id list.
-    Returns one float64 array [n_samples, 3] = (x, y, heading) per agent, sample k at time (k+1)*dt accumulated like
-    the reference (time_step += dt)."""
+    Returns one float64 array [n_samples, 3] = (x, y, heading) per agent.
+
+    The reference advances one clock per agent (`time_step += dt`) through all legs of the route; sample k therefore sits at the
+    k-fold running sum of dt -- np.cumsum reproduces that accumulation exactly -- and leg i owns the samples from where leg i-1
+    stopped up to the first clock value >= its `stay` time.  Inside a leg the samples before `reach` interpolate between the
+    two stops (same expression, evaluated on the whole slice at once), the others sit on the stop."""
     depot = np.asarray(depot, np.float64)
-    loc = lambda t: depot if t == -1 else np.asarray(task_xy[t], np.float64)
+    horizon = float(current_time)
+    for route, arrival in routes:
+        if len(arrival):
+            horizon = max(horizon, float(np.max(arrival)) + float(max_waiting_time), float(np.max(time_finish)) if len(time_finish) else 0.0)
+    n_clock = int(horizon / dt) + 16
+    clock = np.concatenate([[0.0], np.cumsum(np.full(n_clock, dt, np.float64))])            # clock[m]: the value after m increments
     out = []
     for aid, (route, arrival) in enumerate(routes):
-        traj = []
-        time_step = 0
-        angle = 0.0
-        for i in range(len(route)):
-            # (route[i-1] with i == 0 is route[-1] in the reference, :380; its value is only used through prev_decision,
-            # which is 0 for the depot -- restated literally)
-            prev_t = route[i - 1] if i > 0 and route[i - 1] != -1 else -1
-            cur_t = route[i]
-            p, c = loc(prev_t), loc(cur_t)
-            angle = np.arctan2(c[1] - p[1], c[0] - p[0])                                   # :382-383
-            distance = np.linalg.norm(p - c)                                               # :384
-            total_time = distance / velocity                                               # :385
-            arr_cur = arrival[i]
-            arr_prev = arrival[i - 1] if prev_t != -1 else 0                               # :387
-            if cur_t != -1 and aid in members[cur_t] and feasible[cur_t]:                  # :388-393
-                next_decision = time_finish[cur_t] if time_start[cur_t] - arr_cur <= max_waiting_time \
-                    else arr_cur + max_waiting_time
-            else:
-                next_decision = arr_cur + max_waiting_time                                 # :394-395
-            if prev_t == -1:
-                prev_decision = 0                                                          # :396-397
-            elif aid in members[prev_t] and time_start[prev_t] - arr_prev <= max_waiting_time and feasible[prev_t]:
-                prev_decision = time_finish[prev_t]                                        # :399-402
-            else:
-                prev_decision = arr_prev + max_waiting_time                                # :403-404
-            while time_step < next_decision:                                               # :405-414
-                time_step += dt
-                if time_step < arr_cur:
-                    f = (time_step - prev_decision) / total_time
-                    traj.append(np.hstack([p[0] + f * (c[0] - p[0]), p[1] + f * (c[1] - p[1]), angle]))
-                else:
-                    traj.append(np.array([c[0], c[1], angle]))
-        while time_step < current_time:                                                    # :415-417
-            time_step += dt
-            traj.append(np.array([depot[0], depot[1], angle]))
-        out.append(np.array(traj, np.float64).reshape(-1, 3))
+        rows = []
+        done = 0                                                                           # increments taken so far
+        heading_last = 0.0
+        if len(route):
+            src, dst, heading, duration, leave, reach, stay = _leg_table(aid, route, arrival, depot, task_xy, members, feasible,
+                                                                          time_start, time_finish, max_waiting_time, velocity)
+            for i in range(len(route)):
+                upto = max(done, int(np.searchsorted(clock, stay[i], side="left")))        # first m with clock[m] >= stay (:405)
+                t = clock[done + 1:upto + 1]
+                frac = (t - leave[i]) / duration[i] if duration[i] != 0 else np.full(t.shape, np.nan)
+                moving = t < reach[i]                                                      # :407
+                leg = np.empty((len(t), 3), np.float64)
+                leg[:, 0] = np.where(moving, src[i, 0] + frac * (dst[i, 0] - src[i, 0]), dst[i, 0])   # :409-411 / :413
+                leg[:, 1] = np.where(moving, src[i, 1] + frac * (dst[i, 1] - src[i, 1]), dst[i, 1])
+                leg[:, 2] = heading[i]
+                rows.append(leg)
+                done = upto
+                heading_last = heading[i]
+        upto = max(done, int(np.searchsorted(clock, current_time, side="left")))           # :415-417: parked at the depot afterwards
+        tail = np.empty((upto - done, 3), np.float64)
+        tail[:, 0], tail[:, 1], tail[:, 2] = depot[0], depot[1], heading_last
+        rows.append(tail)
+        out.append(np.concatenate(rows, axis=0) if rows else np.zeros((0, 3)))
     return out
 
 

@@ -33,7 +33,7 @@ class _Summary(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("DCM_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (DCM_ORACLE_LIB: e.g. liboracle_asan.so)
         if not os.path.exists(so):
             so = build()
         L = C.CDLL(so)

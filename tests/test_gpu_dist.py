@@ -107,7 +107,7 @@ def test_config5_replay_line(gpu_device):
     j = json.loads(lines[0])
     assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["agents"] == 100 and j["config"]["tasks"] == 500
     assert j["config"]["envs_total"] == 301 and j["config"]["envs_per_gpu"] == 151 and j["config"]["visibility"] == [20, 20, 10, 100]
-    assert j["roofline"]["kernel"] == "k_replay" and "agent_step" in j["config"]["step_definition"]
+    assert j["roofline"]["kernel"] == "k_replay_fast" and "agent_step" in j["config"]["step_definition"]
     per_pass = j["value"] * j["ms_per_step"] / 1e3
     assert 301 * 100 < per_pass < 301 * 2000          # every agent takes a few steps (routes over the 100 visible tasks + depot)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--envs", "256", "--steps", "2",
@@ -123,7 +123,7 @@ def test_config5_replay_line(gpu_device):
 @pytest.mark.parametrize("extra,check", [
     (["--envs", "512"], lambda j: j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 512 and j["config"]["envs_total"] == 1024),
     (["--config", "4", "--envs", "600"], lambda j: j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 300 and j["config"]["tasks"] == 200),
-    (["--config", "5", "--envs", "200"], lambda j: j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 100 and j["roofline"]["kernel"] == "k_replay"),
+    (["--config", "5", "--envs", "200"], lambda j: j["scaling"] == "strong" and j["config"]["envs_per_gpu"] == 100 and j["roofline"]["kernel"] == "k_replay_fast"),
 ], ids=["config2", "config4", "config5"])
 def test_plain_command_launches_its_own_ranks(gpu_device, extra, check):
     """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1, with NO torch.distributed.run around it: the
@@ -162,9 +162,22 @@ def test_default_line_times_the_other_baseline_configs(gpu_device):
     oc = j["other_configs"]
     assert oc["config4_shard"]["kernel"] == "k_rollout_fast_mc" and oc["config4_shard"]["value"] > 1e8
     assert 8192 * 200 < oc["config4_shard"]["steps_per_pass"] < 8192 * 500           # ~320 decisions per 50A/200T episode
-    assert oc["config5_shard"]["kernel"] == "k_replay" and oc["config5_shard"]["value"] > 1e8
+    assert oc["config5_shard"]["kernel"] == "k_replay_fast" and oc["config5_shard"]["value"] > 1e8
     assert oc["midsize_70A130T"]["kernel"] == "k_rollout_fast_g" and oc["midsize_70A130T"]["value"] > 1e8
     assert 4096 * 3 * 200 < oc["midsize_70A130T"]["steps_per_pass"] < 4096 * 3 * 500   # ~296 decisions per 70A/130T episode
     lk = j["lockstep_kernel"]
     assert lk["kernel"] == "k_step_fast" and 0.2 < lk["frac"] < 1.2 and (lk["traffic_frac"] is None or lk["traffic_frac"] < lk["frac"])
     assert j["cpu_baseline"]["value"] > 0 and j["value"] > 1e6
+    # bench-size oracle parity of the headline workload and of every shard; each shard with its own roofline and CPU baseline
+    assert j["parity"]["envs_checked"] == 4096 and j["parity"]["mismatches"] == 0
+    for name, n_envs in (("config4_shard", 8192), ("config5_shard", 4096), ("midsize_70A130T", 4096)):
+        e = oc[name]
+        assert e["parity"]["envs_checked"] == n_envs and e["parity"]["mismatches"] == 0, name
+        assert e["cpu_baseline"]["value"] > 0 and e["cpu_baseline"]["cores"] >= 1 and e["cpu_baseline"]["kind"] == "port", name
+        assert "frac" in e["roofline"] and "stale" in e["roofline"] or e["roofline"].get("note"), name
+    c3 = oc["config3"]
+    assert c3["steps_per_s_end_to_end"] > 1e4 and 0.5 < c3["policy_share"] < 1.0 and c3["env_ms_per_batched_step"] > 0
+    assert "policy-bound" in c3["note"] and c3["policy_dtype"] == "fp32"
+    lim = j["config"]["limits"]
+    assert lim["members_per_task"] == 5 and lim["members_per_task_wide_handle"] == 16 and lim["A"] == 128 and lim["T"] == 1023
+    assert j["config"]["rank_devices"] and j["config"]["rank_devices"][0].startswith("cuda:")

@@ -246,96 +246,80 @@ def test_masked_action_policy_is_reported(gpu_device):
         r.job(w, w, 0, 6, 9)
 
 
-def test_learner_step_on_runner_output(gpu_device):
-    """driver.py:99-199 against dcmrta_amd.ray_compat: actors, job.remote, wait / get, the experience buffer, a 1024-decision
-    batch, forward, gather, REINFORCE loss, backward, clipped optimizer step -- restated call for call."""
-    import copy
-    import random
+def test_actor_results_are_consumable_by_a_learner(gpu_device):
+    """Contract of what the actor shell hands to a learner (the consumer is driver.py, which is not part of this
+    repo): every job returns nine per-decision lists of equal length that concatenate across jobs and stack into batch tensors
+    of the policy's input shapes (seven of the nine slots are in use); the action slot indexes the policy's log-probabilities; a gradient step on a REINFORCE-style
+    objective built from those tensors is finite and moves the weights; evaluation actors answer testing(seed=...) with one float."""
     from dcmrta_amd import ray_compat as ray
-    from dcmrta_amd.ray_compat import RLRunner
     from dcmrta_amd.policy import AttentionNet
+    from dcmrta_amd.ray_compat import RLRunner
     torch.manual_seed(3)
-    NUM_META_AGENT, BATCH_SIZE, D = 2, 1024, 32
-    factory = lambda: AttentionNet(6, 5, D)
-    ray.init(n_envs=24, net_factory=factory, base_seed=5)
-    device = torch.device(gpu_device)
-    global_network, baseline_network = factory().to(device), factory().to(device)
-    global_optimizer = torch.optim.Adam(global_network.parameters(), lr=1e-4)
-    meta_agents = [RLRunner.remote(i) for i in range(NUM_META_AGENT)]                     # driver.py:99
-    weights, baseline_weights = global_network.state_dict(), baseline_network.state_dict()
-    curr_episode, jobList = 0, []
-    agents_num, tasks_num = 12, 23
-    for meta_agent in meta_agents:                                                          # :116-118
-        jobList.append(meta_agent.job.remote(weights, baseline_weights, curr_episode, agents_num, tasks_num))
-        curr_episode += 1
-    metric_name = ['success_rate', 'makespan', 'time_cost', 'waiting_time', 'travel_dist', 'efficiency']
-    experience_buffer = [[] for _ in range(9)]
-    updates = 0
-    before = copy.deepcopy(global_network.state_dict())
-    for _ in range(2):
-        done_id, jobList = ray.wait(jobList, num_returns=NUM_META_AGENT)                  # :129
-        done_jobs = ray.get(done_id)                                                        # :130
-        random.shuffle(done_jobs)
-        perf_metrics = {n: [] for n in metric_name}
-        for job in done_jobs:                                                               # :135-140
-            jobResults, metrics, info = job
-            for i in range(9):
-                experience_buffer[i] += jobResults[i]
-            for n in metric_name:
-                perf_metrics[n].append(metrics[n])
-        assert set(info) >= {"id", "episode_number"}
-        while len(experience_buffer[0]) >= BATCH_SIZE:                                      # :143-188
-            rollouts = copy.copy(experience_buffer)
-            for i in range(len(rollouts)):
-                rollouts[i] = rollouts[i][:BATCH_SIZE]
-            for i in range(len(experience_buffer)):
-                experience_buffer[i] = experience_buffer[i][BATCH_SIZE:]
-            agent_inputs = torch.stack(rollouts[0], dim=0)
-            task_inputs = torch.stack(rollouts[1], dim=0)
-            action_batch = torch.stack(rollouts[2], dim=0)
-            mask_batch = torch.stack(rollouts[3], dim=0)
-            advantage_batch = torch.stack(rollouts[6], dim=0)
-            reward_batch = torch.stack(rollouts[4], dim=0)
-            index = torch.stack(rollouts[5])
-            assert agent_inputs.shape == (BATCH_SIZE, agents_num, 6) and task_inputs.shape == (BATCH_SIZE, tasks_num + 1, 5)
-            assert action_batch.shape == (BATCH_SIZE, 1) and index.shape == (BATCH_SIZE, 1, 1) and reward_batch.shape == (BATCH_SIZE, 1)
-            logp_list = global_network(task_inputs, agent_inputs, mask_batch)               # :175
-            logp = torch.gather(logp_list, 1, action_batch)                                 # :176
-            entropy = (logp_list * logp_list.exp()).nansum(dim=-1).mean()
-            policy_loss = (- logp * advantage_batch.detach()).mean()
-            global_optimizer.zero_grad()
-            policy_loss.backward()
-            grad_norm = torch.nn.utils.clip_grad_norm_(global_network.parameters(), max_norm=10, norm_type=2)
-            global_optimizer.step()
-            assert torch.isfinite(policy_loss) and torch.isfinite(entropy) and torch.isfinite(grad_norm) and grad_norm > 0
-            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in global_network.parameters())
-            assert (logp > -9000).all()                                                     # sampled actions were never masked
-            updates += 1
-        weights = global_network.state_dict()
-        for meta_agent in meta_agents:                                                      # :197-199
-            jobList.append(meta_agent.job.remote(weights, baseline_weights, curr_episode, agents_num, tasks_num))
-            curr_episode += 1
-    assert updates >= 2 and np.isfinite(np.nanmean(perf_metrics["makespan"]))
-    after = global_network.state_dict()
-    assert any(not torch.equal(before[k], after[k]) for k in before)                        # the learner really moved
-    # evaluation calls of driver.py:241-252: fresh actors, set_baseline_weights, testing(seed=...), kill
-    ray.wait(jobList, num_returns=NUM_META_AGENT)
-    for a in meta_agents:
-        ray.kill(a)
-    test_agent_list = [RLRunner.remote(metaAgentID=i) for i in range(NUM_META_AGENT)]
-    for test_agent in test_agent_list:
-        ray.get(test_agent.set_baseline_weights.remote(baseline_weights))
-    sample_job_list = [test_agent.testing.remote(seed=1000 + j) for j, test_agent in enumerate(test_agent_list)]
-    sample_done_id, _ = ray.wait(sample_job_list, num_returns=NUM_META_AGENT)
-    reward = ray.get(sample_done_id)
-    assert len(reward) == NUM_META_AGENT and all(isinstance(x, float) and x < 0 for x in reward)
-    for a in test_agent_list:
-        ray.kill(a)
-    # a failing call surfaces from get, like a Ray task error
-    bad = RLRunner.remote(0)
+    n_actors, batch, A, T = 2, 1024, 12, 23
+    make_net = lambda: AttentionNet(6, 5, 32)
+    ray.init(n_envs=24, net_factory=make_net, base_seed=5)
+    dev = torch.device(gpu_device)
+    learner, baseline = make_net().to(dev), make_net().to(dev)
+    opt = torch.optim.Adam(learner.parameters(), lr=1e-4)
+    start = {k: v.clone() for k, v in learner.state_dict().items()}
+    actors = [RLRunner.remote(i) for i in range(n_actors)]
+    pool = [[] for _ in range(9)]          # slot order: agent obs, task obs, action, mask, reward, leader index, advantage, ... (worker.py:77-83)
+    episode, n_updates, makespans = 0, 0, []
+    for _round in range(2):
+        handles = []
+        for actor in actors:
+            handles.append(actor.job.remote(learner.state_dict(), baseline.state_dict(), episode, A, T))
+            episode += 1
+        ready, pending = ray.wait(handles, num_returns=n_actors)
+        assert not pending
+        for slots, metrics, info in ray.get(ready):
+            # one entry per recorded decision in the seven slots in use; the last two stay empty (worker.py:20-21 keeps nine)
+            assert len(slots) == 9 and len({len(x) for x in slots[:7]}) == 1 and len(slots[0]) > 0 and slots[7] == [] and slots[8] == []
+            assert {"id", "episode_number"} <= set(info)
+            assert set(metrics) == {"success_rate", "makespan", "time_cost", "waiting_time", "travel_dist", "efficiency"}
+            makespans.append(metrics["makespan"])
+            for k in range(9):
+                pool[k].extend(slots[k])                                                           # plain list concatenation works
+        while len(pool[0]) >= batch:
+            take = [x[:batch] for x in pool]
+            pool = [x[batch:] for x in pool]
+            agents_in, tasks_in = torch.stack(take[0]), torch.stack(take[1])
+            action, mask = torch.stack(take[2]), torch.stack(take[3])
+            reward, leader, advantage = torch.stack(take[4]), torch.stack(take[5]), torch.stack(take[6])
+            assert agents_in.shape == (batch, A, 6) and agents_in.dtype == torch.float32
+            assert tasks_in.shape == (batch, T + 1, 5) and tasks_in.dtype == torch.float32
+            assert mask.shape == (batch, T + 1) and mask.dtype == torch.bool
+            assert action.shape == (batch, 1) and action.dtype == torch.int64 and int(action.min()) >= 0 and int(action.max()) <= T
+            assert leader.shape == (batch, 1, 1) and reward.shape == (batch, 1) and advantage.shape[0] == batch
+            logp_all = learner(tasks_in, agents_in, mask)
+            chosen = logp_all.gather(1, action)                       # the action slot addresses the policy output directly
+            assert bool((chosen > -9000).all())                       # no recorded action was a masked one
+            loss = -(chosen * advantage.detach()).mean()
+            opt.zero_grad()
+            loss.backward()
+            gnorm = torch.nn.utils.clip_grad_norm_(learner.parameters(), 10.0)
+            opt.step()
+            assert torch.isfinite(loss) and torch.isfinite(gnorm) and float(gnorm) > 0
+            assert all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in learner.parameters())
+            n_updates += 1
+    assert n_updates >= 2 and np.isfinite(np.nanmean(makespans))
+    end = learner.state_dict()
+    assert any(not torch.equal(start[k], end[k]) for k in start)      # the learner really moved
+    for actor in actors:
+        ray.kill(actor)
+    # evaluation side: fresh actors take baseline weights and answer a seeded test episode with its return
+    testers = [RLRunner.remote(metaAgentID=i) for i in range(n_actors)]
+    for t in testers:
+        ray.get(t.set_baseline_weights.remote(baseline.state_dict()))
+    answers = ray.get(ray.wait([t.testing.remote(seed=1000 + j) for j, t in enumerate(testers)], num_returns=n_actors)[0])
+    assert len(answers) == n_actors and all(isinstance(x, float) and x < 0 for x in answers)
+    for t in testers:
+        ray.kill(t)
+    # a call that fails inside the actor surfaces from get
+    broken = RLRunner.remote(0)
     with pytest.raises(Exception):
-        ray.get(bad.job.remote({}, {}, 0, 5, 8))
-    ray.kill(bad)
+        ray.get(broken.job.remote({}, {}, 0, 5, 8))
+    ray.kill(broken)
 
 
 def test_rl_test_example_script(gpu_device, tmp_path):

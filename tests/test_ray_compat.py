@@ -1,6 +1,6 @@
 """CPU: the Ray call shapes of dcmrta_amd.ray_compat (driver.py:99,117,129-130,233-272) on a plain Python class -- deferred
 execution, wait / get semantics, error delivery, kill; the GPU-backed RLRunner itself is exercised by
-tests/test_gpu_runner.py::test_learner_step_on_runner_output."""
+tests/test_gpu_runner.py::test_actor_results_are_consumable_by_a_learner."""
 import pytest
 
 

@@ -5,7 +5,7 @@ R=${1:-r04}
 python tools/collect_profile.py ${R}_s4 ${R}_streams4 k_rollout_fast > /dev/null
 python tools/collect_profile.py ${R}_s1 ${R}_streams1 k_rollout_fast > /dev/null        # last: the source of config 2's counters.json entry
 python tools/collect_profile.py ${R}_c4 ${R}_config4 k_rollout_fast_mc > /dev/null
-python tools/collect_profile.py ${R}_c5 ${R}_config5 k_replay > /dev/null
+python tools/collect_profile.py ${R}_c5 ${R}_config5 k_replay_fast > /dev/null
 python tools/collect_profile.py ${R}_c5gen ${R}_config5_generalised k_replay > /dev/null
 python tools/collect_profile.py ${R}_c5static ${R}_config5_static k_replay > /dev/null
 python tools/collect_profile.py ${R}_15A35T ${R}_15A35T k_rollout_fast > /dev/null

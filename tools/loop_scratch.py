@@ -5,7 +5,7 @@
 
 Compiles dcmrta_env.hip to gfx950 assembly (`make -C dcmrta_amd/csrc asm`), and for every matching kernel walks the compiler's own
 loop annotations (`; in Loop: Header=BBx_y Depth=N`, `; Parent Loop BBx_y`) to find the DECISION loop -- the loop that contains the
-follower-placement `v_writelane_b32 ..., m0` of decide() -- and counts the scratch (spill) instructions inside that loop and its
+distance sqrt (`v_rsq_f64`) of decide() -- and counts the scratch (spill) instructions inside that loop and its
 child loops, next to the kernel's total.  A kernel whose compiler report shows scratch can still have a spill-free decision loop:
 the spills then sit in the once-per-episode general code (reset, terminal metrics, first event)."""
 import os
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dcmrta_amd", "csrc")
-ASM = os.path.join(CSRC, "dcmrta_env.gfx950.s")
+ASM = os.environ.get("LOOP_SCRATCH_ASM") or os.path.join(CSRC, "dcmrta_env.gfx950.s")      # (LOOP_SCRATCH_ASM + LOOP_SCRATCH_KEEP_ASM=1: another build)
 
 
 def kernels(lines):
@@ -67,7 +67,7 @@ def analyse(body):
             h = parent.get(h)
         return out
 
-    marker = [i for i, l in enumerate(body) if "v_writelane_b32" in l and "m0" in l]
+    marker = [i for i, l in enumerate(body) if "v_rsq_f64" in l]      # the sqrt of decide()'s distance: the only one in these kernels
     total = sum(1 for l in body if re.match(r"\s+scratch_(load|store)", l))
     if not marker:
         return None, total, None, 0
