@@ -316,43 +316,67 @@ def config3_probe(dev, B=4096, A=20, T=50, warm=30, n=150):
     return out
 
 
-def other_config_shards(dev, visibility, passes=4):
+def other_config_shards(dev, visibility, passes=8):
     """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 8192 envs x
     100A/500T route replay with dynamic arrivals), one mid-size shape (4096 envs x 70A/130T) and BASELINE configs[2] (attention
     policy in the loop), timed inside the DEFAULT run so that whoever clocks `python bench.py` also clocks them: one warm pass,
-    then `passes` passes back to back, one stream, inputs resident in HBM.  Each entry carries its issue roofline (committed
+    then `passes` passes back to back, inputs resident in HBM.  Each entry carries its issue roofline (committed
     counters of that kernel), a CPU baseline (the oracle on the same shard, all usable cores) and the oracle parity of the
     shard.  The full lines of these configs (sharding, streams) are `bench.py --config 4` / `--config 5`."""
     out = {}
     cores = usable_cores()
+    side = [torch.cuda.Stream(device=dev) for _ in range(max(AUTO_STREAM_CANDIDATES))]
+    main_stream = torch.cuda.current_stream(dev)
+
+    def timed(c, B, eps, S, n_pass):
+        """`n_pass` passes of S sub-batches back to back (one warm pass first); returns (seconds, steps, sub-batches)."""
+        subs = [SubBatch(c, lo, hi - lo, dev, main_stream if S == 1 else side[k], visibility)
+                for k, (lo, hi) in enumerate(shard_range(B, k, S) for k in range(S))]
+        counts = []
+        for rep in (1, n_pass):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(rep):
+                for sb in subs:
+                    with torch.cuda.stream(sb.stream):
+                        counts.append(sb.run(eps, True)[0])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            if rep == 1:
+                counts = []
+        return dt, int(sum(int(x.sum().item()) for x in counts)), subs
     mid = dict(CONFIGS["2"], agents=70, tasks=130, episodes=3)     # a mid-size shape (env/task_env.py:57-65 draws sizes from ranges)
     for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
         A, T = cfg["agents"], cfg["tasks"]
         c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else replay_kernel_name(A, T, 5, True, visibility[3]),
                  episodes=eps)
-        sb = SubBatch(c, 0, B, dev, torch.cuda.current_stream(dev), visibility)
-        sb.run(eps, True)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        counts = [sb.run(eps, True)[0] for _ in range(passes)]
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        n = int(torch.stack(counts).sum().item())
+        # like the headline workload the shard is cut into sub-batches on separate HIP streams when that pays (a launch lasts as
+        # long as its slowest env: with several independent streams one sub-batch's tail overlaps with the others' bodies):
+        # 4 / 2 / 1 are tried with two passes each, the best is timed
+        trial = {}
+        for S in AUTO_STREAM_CANDIDATES:
+            dt_, _, subs_ = timed(c, B, eps, S, 2)
+            trial[S] = dt_ / 2
+            for sb in subs_:
+                sb.env.close()
+        S = min(trial, key=trial.get)
+        dt, n, subs = timed(c, B, eps, S, passes)
         what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
-            "random-policy rollout at a mid-size shape, 3 episodes per env per pass, one stream"
+            "random-policy rollout at a mid-size shape, 3 episodes per env per pass"
         out[name] = {"workload": f"{B} envs x {A}A/{T}T, {what}", "kernel": c["kernel"],
                      "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes,
+                     "streams": S, "stream_trial_ms_per_pass": {str(k): v * 1e3 for k, v in trial.items()},
                      "roofline": shard_roofline(c["kernel"], A, T, n / passes, dt / passes)}
-        if sb.replay:
-            ne, bad, units, osec = parity_replay(sb, A, visibility, cores)
-            fields = PARITY_FIELDS_REPLAY
-        else:
-            ne, bad, units, osec = parity_rollout(sb, A, eps, cores)
-            fields = PARITY_FIELDS_ROLLOUT
-        out[name]["parity"] = {"envs_checked": ne, "mismatches": bad, "fields": fields}
+        ne = bad = units = 0
+        osec = 0.0
+        for sb in subs:
+            r = parity_replay(sb, A, visibility, cores, max_envs=4096 // S) if sb.replay else parity_rollout(sb, A, eps, cores)
+            ne, bad, units, osec = ne + r[0], bad + r[1], units + r[2], osec + r[3]
+        out[name]["parity"] = {"envs_checked": ne, "mismatches": bad, "fields": PARITY_FIELDS_REPLAY if subs[0].replay else PARITY_FIELDS_ROLLOUT}
         out[name]["cpu_baseline"] = {"value": units / osec, "unit": "steps/s", "cores": cores, "kind": "port",
                                      "sample": f"{ne} envs of this shard, one pass ({units} steps), oracle C port, {cores} threads"}
-        sb.env.close()
+        for sb in subs:
+            sb.env.close()
     out["config3"] = config3_probe(dev)
     return out
 

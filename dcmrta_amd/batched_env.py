@@ -40,6 +40,10 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# hipStream_t of torch's current stream on a device as a plain int (the raw accessor skips the Stream object)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+
+
 class BatchedTaskEnv:
     def __init__(self, n_envs, n_agents, n_tasks, device="cuda:0", max_waiting_time=10.0, max_time=100.0,
                  individual_selection=False, auto_reset=False, auto_reset_episodes=0, strict_mask=False, member_cap=5):
@@ -81,6 +85,12 @@ class BatchedTaskEnv:
         self._active = torch.empty((B,), dtype=torch.uint8, device=dev)
         self._instances = None
         self.n_agents = self.n_tasks = None
+        # the lockstep hot path (step() once per decision of a policy in the loop): everything that does not change between calls is
+        # bound once -- the output pointers as plain ints, the Observation over the static buffers, the entry point
+        self._out_ptrs = tuple(int(t.data_ptr()) for t in (self._agents, self._tasks, self._mask, self._leader, self._active))
+        self._obs_static = Observation(self._agents, self._tasks, self._mask.view(torch.bool), self._leader, self._active.view(torch.bool))
+        self._dcm_step = self._lib.dcm_step
+        self._dev_index = idx
         # bumped whenever something a captured HIP graph of dcm_step has baked in changes (raggedness of the batch: the
         # per-env sizes pointer and the kernel instantiation; the route-log pointers): GraphedRollout re-captures
         self.graph_epoch = 0
@@ -164,8 +174,7 @@ class BatchedTaskEnv:
 
     # ------------------------------------------------------------------ observe / step
     def _obs(self):
-        return Observation(self._agents, self._tasks, self._mask.view(torch.bool), self._leader,
-                           self._active.view(torch.bool))
+        return self._obs_static
 
     def observe(self, leader=None):
         li = None if leader is None else self._dev(leader, torch.int32)
@@ -177,6 +186,14 @@ class BatchedTaskEnv:
     def step(self, actions, leader=None, n_followers=None, followers=None, observe=True):
         """actions int32[B] (0 = depot, k = task k-1).  Optional injected choices for parity replays:
         leader int32[B] (-1 = draw), n_followers int32[B] (-1 = draw), followers int16[B,4]."""
+        if (leader is None and n_followers is None and followers is None and observe and type(actions) is torch.Tensor
+                and actions.dtype is torch.int32 and actions.is_cuda and actions.is_contiguous()
+                and actions.device.index == self._dev_index and actions.numel() == self.B and torch.cuda.current_device() == self._dev_index):
+            # the plain call of a policy in the loop (worker.py:73-76): no conversions, no device switch, no per-call allocation
+            rc = self._dcm_step(self._h, actions.data_ptr(), None, None, None, *self._out_ptrs, _RAW_STREAM(self._dev_index))
+            if rc != 0:
+                check(rc)
+            return self._obs_static
         a = self._dev(actions, torch.int32)
         li = None if leader is None else self._dev(leader, torch.int32)
         nf = None if n_followers is None else self._dev(n_followers, torch.int32)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # condense the gpurun_out/prof_* directories of the round's evidence run (tools/evidence_run.sh) into profiles/ (run in the build container)
 set -e
-R=${1:-r04}
+R=${1:-r05}
 python tools/collect_profile.py ${R}_s4 ${R}_streams4 k_rollout_fast > /dev/null
 python tools/collect_profile.py ${R}_s1 ${R}_streams1 k_rollout_fast > /dev/null        # last: the source of config 2's counters.json entry
 python tools/collect_profile.py ${R}_c4 ${R}_config4 k_rollout_fast_mc > /dev/null

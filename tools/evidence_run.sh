@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's evidence run (on the GPU box through gpurun): every rocprofv3 profile behind profiles/ + the contract lines.
 #   gpurun --timeout 3000 -- bash tools/evidence_run.sh r04      then, in the build container:  bash tools/collect_all.sh r04
-R=${1:-r04}
+R=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 bash tools/profile.sh ${R}_s4 --streams 4
@@ -20,4 +20,9 @@ python bench.py --config 4 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config4
 python bench.py --config 5 --steps 10 --warmup 2 > gpurun_out/${R}_bench_config5.json 2>> gpurun_out/${R}_bench.err
 python bench.py --config 5 --steps 10 --warmup 2 --visibility 100,100,10,500 > gpurun_out/${R}_bench_config5_generalised.json 2>> gpurun_out/${R}_bench.err
 python bench.py --config 5 --steps 10 --warmup 2 --visibility static > gpurun_out/${R}_bench_config5_static.json 2>> gpurun_out/${R}_bench.err
+# keep only what tools/collect_*.py read (gpurun copies back at most 64 MiB): the stats / counter CSVs, the logs, the commands
+echo "gpurun_out before pruning: $(du -sh gpurun_out | cut -f1)"
+find gpurun_out/prof_* -type f ! \( -name '*kernel_stats.csv' -o -name '*counter_collection.csv' -o -name '*.log' -o -name 'command.txt' \) -delete
+find gpurun_out/prof_* -type f -name '*.log' -size +256k -exec sh -c 'tail -c 65536 "$1" > "$1.t" && mv "$1.t" "$1"' _ {} \;
+echo "gpurun_out after pruning: $(du -sh gpurun_out | cut -f1)"
 tail -c 300 gpurun_out/${R}_bench.json
