@@ -344,8 +344,10 @@ class BatchedTaskEnv:
         return self
 
     def set_replay_placement(self, placement="auto"):
-        """Where execute_routes keeps the replay state that is off the event loop's critical path: "auto" (LDS for batches of at
-        most four envs per CU, else HBM), "lds" or "hbm" (dcm_set_replay_placement).  Results do not depend on it."""
+        """Which replay kernel execute_routes runs: "auto" = the register-resident one whenever the shape allows it (<= 128 agents,
+        <= 128 live tasks, member_cap <= 8), else the general one with its replay scratch in LDS for batches of at most four envs
+        per CU and in HBM otherwise; "lds" / "hbm" = always the general kernel with its scratch there (dcm_set_replay_placement).
+        Results do not depend on it."""
         check(self._lib.dcm_set_replay_placement(self._h, {"auto": 0, "lds": 1, "hbm": 2}[placement]))
         return self
 

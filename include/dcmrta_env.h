@@ -255,11 +255,16 @@ int dcm_load_routes(dcm_env *env, const int32_t *routes, const int32_t *route_le
  * Needs initial >= 0, batch >= 1, period >= 1, cap >= initial.  Host-side setter; takes effect at the next dcm_execute_routes. */
 int dcm_set_visibility(dcm_env *env, int32_t initial, int32_t batch, int32_t period, int32_t cap);
 
-/* Where dcm_execute_routes keeps the part of the replay state that is off the event loop's critical path (member arrival
- * times, time_finish, wake-up times, travel distance, latest arrival; "replay scratch", allocated by dcm_load_routes:
- * 8 T (member_cap + 1) + 16 A + 4 T bytes per env).  0 = auto (default): in LDS when the batch has at most four envs per
- * CU -- every env is resident at once anyway and one wave's latency is what counts -- else in HBM, which leaves 14 instead
- * of 4 waves per CU resident at 100A/500T; 1 = LDS, 2 = HBM (for tests / measurements).  Results do not depend on it. */
+/* Which replay kernel dcm_execute_routes runs and where it keeps its state.
+ * 0 = auto (default): the register-resident kernel whenever the shape allows it -- at most 128 agents, member_cap <= 8, and at
+ *     most 128 LIVE tasks, i.e. tasks that can ever get a member: all of them without dynamic arrivals, tasks 1..cap with them
+ *     (an agent is never sent to a task that is not visible yet, env/task_env.py:578-584, and visible <= cap, :567).  BASELINE
+ *     config 5 (100A/500T at the reference's cap of 100) and every 20A/50T-class replay qualify.  Otherwise the general kernel,
+ *     with its "replay scratch" (member arrival times, time_finish, wake-up times, travel distance, latest arrival; allocated by
+ *     dcm_load_routes: 8 T (member_cap + 1) + 16 A + 4 T bytes per env) in LDS when the batch has at most four envs per CU --
+ *     every env is resident at once anyway and one wave's latency is what counts -- else in HBM.
+ * 1 / 2: always the general kernel, replay scratch in LDS / in HBM (for tests and measurements).
+ * Results do not depend on it. */
 int dcm_set_replay_placement(dcm_env *env, int32_t placement);
 
 /* execute_by_route (env/task_env.py:562-593; max_waiting_time 100, cut-off 200) followed by get_episode_reward

@@ -287,3 +287,35 @@ def test_three_episodes_in_one_launch_against_the_oracle(gpu_device, oracle_lib,
             d0 += ref["n_steps"]
         assert steps[b] == d0, (b, steps[b], d0)
         H.assert_final_matches(fin[b], ref, f"{A}A{T}T env{b} third episode")
+
+
+@pytest.mark.parametrize("mwt", [0.0, 10.0])
+def test_zero_max_waiting_time_takes_the_literal_rule(gpu_device, oracle_lib, mwt):
+    """max_waiting_time = 0: a member that arrives at the very moment of an event has already "waited" (now - arrival >= 0,
+    env/task_env.py:269) and is dropped at once.  The register-resident kernels skip the task_update pass of a quiet join on the
+    ground that a fresh member has not waited, which needs max_waiting_time > 0: such a handle runs the general kernels (persistent
+    and lockstep), which evaluate the rule literally -- and both match the oracle."""
+    import torch
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 12, 20, 50
+    inst = generate_batch(B, A, T, base_seed=321)
+    seeds = env_seeds(4, 0, B)
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, max_waiting_time=mwt).load_instances(**inst)
+    env.reset(seeds, observe=False)
+    steps = env.rollout_random(episodes=1).cpu().numpy()
+    fin = H.gpu_final(env)
+    for b in range(B):
+        o = oracle_lib.OracleEnv(A, T, max_waiting_time=mwt).load(inst["depot"][b], inst["task_xy"][b], inst["req"][b], inst["dur"][b])
+        ref = o.rollout(int(seeds[b]), 0, oracle_lib.POLICY_RANDOM, cap_steps=50000, record=False)
+        assert steps[b] == ref["n_steps"], (b, steps[b], ref["n_steps"])
+        H.assert_final_matches(fin[b], ref, f"mwt={mwt} env{b}")
+    # the lockstep API under the same parameter: the first 40 decisions of env 0 against the oracle's trace
+    obs = env.reset(seeds)
+    o = oracle_lib.OracleEnv(A, T, max_waiting_time=mwt).load(inst["depot"][0], inst["task_xy"][0], inst["req"][0], inst["dur"][0])
+    ref = o.rollout(int(seeds[0]), 0, oracle_lib.POLICY_FIRST, cap_steps=40, allow_cap=True)
+    for i in range(min(40, ref["n_steps"])):
+        assert int(obs.leader[0]) == int(ref["leader"][i]) and np.array_equal(obs.mask[0].cpu().numpy().astype(np.uint8), ref["mask"][i]), i
+        assert np.array_equal(obs.tasks[0].cpu().numpy().view(np.uint32), ref["tasks_obs"][i].view(np.uint32)), i
+        obs = env.step(torch.argmax((~obs.mask).to(torch.int32), dim=1).int())
