@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's contract lines (configs 2 / 4 / 5 + the two extra replay schedules), run AFTER tools/collect_all.sh has put the
 # round's counters into profiles/counters.json, so that every line carries its roofline.   gpurun -- bash tools/bench_lines.sh r04
-R=${1:-r04}
+R=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err

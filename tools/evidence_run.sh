@@ -24,5 +24,10 @@ python bench.py --config 5 --steps 10 --warmup 2 --visibility static > gpurun_ou
 echo "gpurun_out before pruning: $(du -sh gpurun_out | cut -f1)"
 find gpurun_out/prof_* -type f ! \( -name '*kernel_stats.csv' -o -name '*counter_collection.csv' -o -name '*.log' -o -name 'command.txt' \) -delete
 find gpurun_out/prof_* -type f -name '*.log' -size +256k -exec sh -c 'tail -c 65536 "$1" > "$1.t" && mv "$1.t" "$1"' _ {} \;
+# the counter CSVs hold one row per dispatch and counter of EVERY kernel of the process (torch's included): keep the env kernels' rows
+for f in $(find gpurun_out/prof_* -type f -name '*counter_collection.csv'); do
+  awk 'NR == 1 || /k_step|k_rollout|k_replay|k_observe|k_reset/' "$f" > "$f.t" && mv "$f.t" "$f"
+done
+du -a gpurun_out | sort -n | tail -5
 echo "gpurun_out after pruning: $(du -sh gpurun_out | cut -f1)"
 tail -c 300 gpurun_out/${R}_bench.json
