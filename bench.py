@@ -310,7 +310,7 @@ def config3_probe(dev, B=4096, A=20, T=50, warm=30, n=150):
     return out
 
 
-def other_config_shards(dev, visibility, passes=8):
+def other_config_shards(dev, visibility, passes=12):
     """BASELINE configs[3] and configs[4] on their per-GPU shard of an 8-GPU node (8192 envs x 50A/200T rollout; 8192 envs x
     100A/500T route replay with dynamic arrivals), one mid-size shape (4096 envs x 70A/130T) and BASELINE configs[2] (attention
     policy in the loop), timed inside the DEFAULT run so that whoever clocks `python bench.py` also clocks them: one warm pass,
@@ -346,11 +346,11 @@ def other_config_shards(dev, visibility, passes=8):
                  episodes=eps)
         # like the headline workload the shard is cut into sub-batches on separate HIP streams when that pays (a launch lasts as
         # long as its slowest env: with several independent streams one sub-batch's tail overlaps with the others' bodies):
-        # 4 / 2 / 1 are tried with two passes each, the best is timed
+        # 4 / 2 / 1 are tried with four passes each, the best is timed
         trial = {}
         for S in AUTO_STREAM_CANDIDATES:
-            dt_, _, subs_ = timed(c, B, eps, S, 2)
-            trial[S] = dt_ / 2
+            dt_, _, subs_ = timed(c, B, eps, S, 4)
+            trial[S] = dt_ / 4
             for sb in subs_:
                 sb.env.close()
         S = min(trial, key=trial.get)
