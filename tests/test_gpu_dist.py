@@ -140,6 +140,9 @@ def test_plain_command_launches_its_own_ranks(gpu_device, extra, check):
     assert j["config"]["world"] == 2 and j["config"]["process_group_ranks"] == 2 and j["config"]["dist_backend"] == "gloo"
     assert j["config"]["self_launched"] is True and check(j)
     assert "cpu_baseline" not in j
+    # every rank compared its own block with the oracle after the timed region; the counts are summed over the group
+    assert j["parity"]["mismatches"] == 0 and j["parity"]["envs_checked"] == j["config"]["envs_total"]
+    assert len(j["config"]["rank_devices"]) == 2
 
 
 def test_plain_command_propagates_rank_failure(gpu_device):
