@@ -184,3 +184,16 @@ def test_default_line_times_the_other_baseline_configs(gpu_device):
     lim = j["config"]["limits"]
     assert lim["members_per_task"] == 5 and lim["members_per_task_wide_handle"] == 16 and lim["A"] == 128 and lim["T"] == 1023
     assert j["config"]["rank_devices"] and j["config"]["rank_devices"][0].startswith("cuda:")
+
+
+def test_unprofiled_shape_borrows_the_counters_of_its_kernel(gpu_device):
+    """A shape without a committed PMC profile is priced with the instruction counts of the profiled shape that runs the SAME kernel,
+    and the line says so (`roofline.counters_shape`): the mid-size class borrows 70A/130T's, a one-chunk training shape 20A/50T's."""
+    for extra, kernel, shape in ((["--agents", "65", "--tasks", "65"], "k_rollout_fast_g", "70A130T"),
+                                 (["--agents", "12", "--tasks", "30"], "k_rollout_fast", "20A50T")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--envs", "512", "--steps", "2", "--warmup", "1", "--streams", "1",
+                              "--no-cpu-baseline", "--no-lockstep-probe"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-2500:]
+        r = json.loads(lines[0])["roofline"]
+        assert r["kernel"] == kernel and r["counters_shape"] == shape and r["frac"] is not None and r["frac"] > 0
