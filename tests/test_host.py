@@ -283,7 +283,7 @@ def test_issue_roofline_pricing():
     import json
     allc = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
     assert len({v.get("build_id") for v in allc.values()}) == 1 and all(v.get("build_id") for v in allc.values())
-    for key in ("k_rollout_fast:20A50T", "k_rollout_fast_mc:50A200T", "k_replay:100A500T", "k_step:4096x20A50T", "k_step:65536x20A50T"):
+    for key in ("k_rollout_fast:20A50T", "k_rollout_fast_mc:50A200T", "k_replay_fast:100A500T", "k_step:4096x20A50T", "k_step:65536x20A50T"):
         assert key in allc, key                                         # every BASELINE config's dominant kernel has a profile
     # a kernel whose scalar-unit time exceeds even the upper VALU price is bound by the CU's one scalar unit
     c3 = dict(c, **{"SQ_INSTS_SALU_per_decision": 400.0})
@@ -295,7 +295,11 @@ def test_issue_roofline_pricing():
 def test_kernel_name_helpers_follow_the_dispatch():
     """roofline.rollout_kernel_name / step_kernel_name (which rocprofv3 kernel a bench line is priced with) restate the shape
     dispatch of dcm_rollout_random / dcm_step (csrc/dcmrta_env.hip): one-chunk layouts, 50A/200T, the mid-size class, the rest."""
-    from dcmrta_amd.roofline import rollout_kernel_name, step_kernel_name
+    from dcmrta_amd.roofline import replay_kernel_name, rollout_kernel_name, step_kernel_name
+    # dcm_execute_routes (csrc/dcmrta_replay.hip): the register-resident kernel up to 128 agents / 128 LIVE tasks / 8 member slots
+    assert replay_kernel_name(100, 500, 5, True, 100) == replay_kernel_name(20, 50, 8, False, 100) == "k_replay_fast"
+    assert replay_kernel_name(100, 500, 5, False, 100) == replay_kernel_name(100, 500, 5, True, 500) == "k_replay"
+    assert replay_kernel_name(20, 50, 16, False, 100) == "k_replay" and replay_kernel_name(100, 128, 5, False, 100) == "k_replay_fast"
     assert rollout_kernel_name(20, 50) == rollout_kernel_name(15, 35) == rollout_kernel_name(64, 63) == "k_rollout_fast"
     assert rollout_kernel_name(50, 200) == "k_rollout_fast_mc"
     for shape in ((70, 130), (65, 65), (128, 256), (30, 100), (100, 64), (64, 65), (65, 10)):
