@@ -341,37 +341,43 @@ def other_config_shards(dev, visibility, passes=12):
         return dt, int(sum(int(x.sum().item()) for x in counts)), subs
     mid = dict(CONFIGS["2"], agents=70, tasks=130, episodes=3)     # a mid-size shape (env/task_env.py:57-65 draws sizes from ranges)
     for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
-        A, T = cfg["agents"], cfg["tasks"]
-        c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else replay_kernel_name(A, T, 5, True, visibility[3]),
-                 episodes=eps)
-        # like the headline workload the shard is cut into sub-batches on separate HIP streams when that pays (a launch lasts as
-        # long as its slowest env: with several independent streams one sub-batch's tail overlaps with the others' bodies):
-        # 4 / 2 / 1 are tried with four passes each, the best is timed
-        trial = {}
-        for S in AUTO_STREAM_CANDIDATES:
-            dt_, _, subs_ = timed(c, B, eps, S, 4)
-            trial[S] = dt_ / 4
-            for sb in subs_:
+        try:
+            A, T = cfg["agents"], cfg["tasks"]
+            c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else replay_kernel_name(A, T, 5, True, visibility[3]),
+                     episodes=eps)
+            # like the headline workload the shard is cut into sub-batches on separate HIP streams when that pays (a launch lasts as
+            # long as its slowest env: with several independent streams one sub-batch's tail overlaps with the others' bodies):
+            # 4 / 2 / 1 are tried with four passes each, the best is timed
+            trial = {}
+            for S in AUTO_STREAM_CANDIDATES:
+                dt_, _, subs_ = timed(c, B, eps, S, 4)
+                trial[S] = dt_ / 4
+                for sb in subs_:
+                    sb.env.close()
+            S = min(trial, key=trial.get)
+            dt, n, subs = timed(c, B, eps, S, passes)
+            what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
+                "random-policy rollout at a mid-size shape, 3 episodes per env per pass"
+            out[name] = {"workload": f"{B} envs x {A}A/{T}T, {what}", "kernel": c["kernel"],
+                         "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes,
+                         "streams": S, "stream_trial_ms_per_pass": {str(k): v * 1e3 for k, v in trial.items()},
+                         "roofline": shard_roofline(c["kernel"], A, T, n / passes, dt / passes)}
+            ne = bad = units = 0
+            osec = 0.0
+            for sb in subs:
+                r = parity_replay(sb, A, visibility, cores, max_envs=4096 // S) if sb.replay else parity_rollout(sb, A, eps, cores)
+                ne, bad, units, osec = ne + r[0], bad + r[1], units + r[2], osec + r[3]
+            out[name]["parity"] = {"envs_checked": ne, "mismatches": bad, "fields": PARITY_FIELDS_REPLAY if subs[0].replay else PARITY_FIELDS_ROLLOUT}
+            out[name]["cpu_baseline"] = {"value": units / osec, "unit": "steps/s", "cores": cores, "kind": "port",
+                                         "sample": f"{ne} envs of this shard, one pass ({units} steps), oracle C port, {cores} threads"}
+            for sb in subs:
                 sb.env.close()
-        S = min(trial, key=trial.get)
-        dt, n, subs = timed(c, B, eps, S, passes)
-        what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
-            "random-policy rollout at a mid-size shape, 3 episodes per env per pass"
-        out[name] = {"workload": f"{B} envs x {A}A/{T}T, {what}", "kernel": c["kernel"],
-                     "value": n / dt, "unit": "steps/s", "ms_per_pass": dt / passes * 1e3, "passes": passes, "steps_per_pass": n / passes,
-                     "streams": S, "stream_trial_ms_per_pass": {str(k): v * 1e3 for k, v in trial.items()},
-                     "roofline": shard_roofline(c["kernel"], A, T, n / passes, dt / passes)}
-        ne = bad = units = 0
-        osec = 0.0
-        for sb in subs:
-            r = parity_replay(sb, A, visibility, cores, max_envs=4096 // S) if sb.replay else parity_rollout(sb, A, eps, cores)
-            ne, bad, units, osec = ne + r[0], bad + r[1], units + r[2], osec + r[3]
-        out[name]["parity"] = {"envs_checked": ne, "mismatches": bad, "fields": PARITY_FIELDS_REPLAY if subs[0].replay else PARITY_FIELDS_ROLLOUT}
-        out[name]["cpu_baseline"] = {"value": units / osec, "unit": "steps/s", "cores": cores, "kind": "port",
-                                     "sample": f"{ne} envs of this shard, one pass ({units} steps), oracle C port, {cores} threads"}
-        for sb in subs:
-            sb.env.close()
-    out["config3"] = config3_probe(dev)
+        except Exception as ex:      # (an auxiliary entry must never take the headline line down with it)
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    try:
+        out["config3"] = config3_probe(dev)
+    except Exception as ex:
+        out["config3"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return out
 
 
@@ -574,7 +580,12 @@ def main():
             flags = sb.env.status()["flags"].cpu().numpy()
             assert (flags & 0x138).sum() == 0, "env error flags set"
     # (right after the timed region, before any host-only work lets the GPU clock down)
-    lockstep = lockstep_kernel_probe(A, T, dev) if (ctx.world == 1 and not args.no_lockstep_probe and not replay) else None
+    lockstep = None
+    if ctx.world == 1 and not args.no_lockstep_probe and not replay:
+        try:
+            lockstep = lockstep_kernel_probe(A, T, dev)
+        except Exception as ex:      # (an auxiliary probe must never take the headline line down with it)
+            lockstep = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # Oracle parity at bench size (part of the cpu_baseline leg, after the timed region): every env of this rank's block.
     parity = None
     if not args.no_cpu_baseline:
@@ -684,11 +695,14 @@ def main():
     if ctx.world == 1 and not args.no_cpu_baseline:
         sb = subs[0]
         inst = {k: np.concatenate([x.inst[k] for x in subs]) for k in sb.inst}
-        if replay:
-            # (route arrays of the sub-batches can differ in their cap: the baseline samples the first sub-batch's envs)
-            out["cpu_baseline"] = cpu_baseline_replay(sb.inst, sb.routes, sb.route_len, A, visibility, reactive=not static_replay)
-        else:
-            out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
+        try:
+            if replay:
+                # (route arrays of the sub-batches can differ in their cap: the baseline samples the first sub-batch's envs)
+                out["cpu_baseline"] = cpu_baseline_replay(sb.inst, sb.routes, sb.route_len, A, visibility, reactive=not static_replay)
+            else:
+                out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
+        except Exception as ex:
+            out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     print(json.dumps(out), flush=True)
     ctx.shutdown()
 
