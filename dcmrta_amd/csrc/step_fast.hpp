@@ -102,21 +102,56 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
         store_hdr(h, lane);
         WSYNC();
         // write back what the step can have changed (see k_step)
-        const uint32_t dm = uni(*S.dirty()) | f.dirty;
+        const uint32_t sd = uni(*S.dirty());
+        const uint32_t dm = sd | f.dirty;
         auto put = [&](uint32_t lo, uint32_t hi) {
             lo &= ~15u; hi = (hi + 15u) & ~15u;
             copy16(rec + lo, smem + lo, hi - lo, lane);
         };
         const uint32_t Tn = (uint32_t)S.PT();
-        put(0, L.tb());                                                               // header + agent arrays
-        if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                            // time_start, time_finish
-        if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
-        else {
+        // When only the register-resident step has touched the record (no general code: sd == 0) and it removed nobody, what it
+        // changed of time_start / time_finish / the arrival rows / the member ids belongs to the tasks it names (a join: one
+        // task; tasks that became feasible): their 64-byte pieces of those sections go back instead of the 400-byte sections.
+        const bool fine = sd == 0 && (f.dirty & SimT::DIRTY_ROWS) != SimT::DIRTY_ROWS && !(f.dirty & SimT::DIRTY_NAB);
+        const uint32_t An = (uint32_t)L.A;                 // (the layout's agent count: the pitch of the agent arrays)
+        if (fine && regs && (An & 3u) == 0u) {
+            // header, then the 16-byte pieces of the (contiguous) agent arrays that hold a changed agent: five f64 arrays -- two agents
+            // per piece -- and two 32-bit ones -- four per piece
+            put(0, 64);
+            const uint32_t n8 = An / 2u, n4 = An / 4u, total = 5u * n8 + 2u * n4;
+            for (uint32_t i = lane; i < total; i += WAVE) {
+                const bool wide = i < 5u * n8;
+                const uint32_t c = wide ? i % n8 : (i - 5u * n8) % n4;
+                const uint64_t bits = wide ? (f.achg >> (2u * c)) & 3ull : (f.achg >> (4u * c)) & 15ull;
+                if (bits) ((uint4*)(rec + 64))[i] = ((const uint4*)(smem + 64))[i];
+            }
+        } else put(0, L.tb());                                                        // header + agent arrays
+        if (fine) {
+            auto piece = [&](uint32_t sec, int t) {                                   // the aligned 64 bytes of a f64 / u64 [T] section that hold task t
+                const uint32_t lo = (sec + 8u * (uint32_t)t) & ~63u, end = sec + 8u * Tn;
+                put(lo < sec ? sec : lo, lo + 64u < end ? lo + 64u : end);
+            };
+            for (uint64_t m = f.dt_times; m; m &= m - 1) {
+                const int t = __ffsll((unsigned long long)m) - 1;
+                piece(L.ts(), t); piece(L.tf(), t);
+            }
+            for (uint64_t m = f.dt_join; m; m &= m - 1) {
+                const int t = __ffsll((unsigned long long)m) - 1;
 #pragma unroll
-            for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+                for (int j = 0; j < M; j++) if (dm & (2u << j)) piece(L.marr() + 8u * Tn * j, t);
+                piece(L.mids(), t);
+            }
+            put(L.tinfo(), L.tnab());                                                 // status words
+        } else {
+            if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                        // time_start, time_finish
+            if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
+            else {
+#pragma unroll
+                for (int j = 0; j < M; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+            }
+            if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
+            put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());        // status words (+ abandonment counts)
         }
-        if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
-        put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());            // status words (+ abandonment counts)
     }
     // mask + observation of the next decision (worker.py:57-68), fused
     WSYNC();
