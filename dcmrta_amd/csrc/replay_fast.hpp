@@ -1,18 +1,17 @@
 // replay_fast.hpp -- register-resident route replay (included by dcmrta_replay.hip, inside its anonymous namespace).
 //
-// execute_by_route (env/task_env.py:562-593) with every field the event loop touches in VGPRs, the design of the round-4 RL
-// kernels (rollout_fast*.hpp) applied to the replay:
+// execute_by_route (env/task_env.py:562-593) with the design of the round-4 RL kernels (rollout_fast*.hpp) applied to the replay:
 //
-//   * lane a of agent chunk i owns agent i*64 + a: position, arrival_time[-1], next_decision, travel_dist, max(arrival_time),
-//     route cursor + next preset action, route[-1], flags, and a CACHE of its current task's time_finish (NaN while that task is
-//     not feasible) -- so agent_update (:207-243) is lane-local arithmetic on all agents at once: the literal reference
-//     semantics (every agent, every call) for the price the LDS version paid for one agent;
+//   * lane a of agent chunk i owns agent i*64 + a: position, arrival_time[-1], next_decision, route cursor + next preset action,
+//     route[-1], flags, a CACHE of its current task's time_finish (NaN while that task is not feasible) and the re-arm quantum
+//     (next - 1) // batch * period of :221 -- so agent_update (:207-243) is lane-local arithmetic on all agents at once: the
+//     literal reference semantics (every agent, every call) for the price the LDS version paid for one agent;
 //   * lane t of task chunk c owns LIVE task c*64 + t: status word, time_finish and the member arrival slots (NaN-padded:
 //     v_min/v_max_f64 ignore them) -- so task_update (:245-281) is lane-local select code on a whole chunk at once; only the
 //     removal of members (rare) runs a wave-uniform loop;
-//   * what the agent_step of agent a on task k reads "by index" is v_readlane from the owning lanes; its results go back
-//     through lane-select moves.  No LDS access, no HBM access and no s_waitcnt on the loop's critical path except the
-//     2-byte LDS read of the agent's next route entry;
+//   * an agent_step reads the deciding agent's action and the joined task's status word with v_readlane and its target's
+//     location + member ids in ONE LDS round trip (wave-uniform address); the distance chain runs on all lanes, each from its own
+//     position, and lane l commits; results go back through lane-select moves;
 //   * LIVE tasks: the tasks that can ever get a member -- all T without dynamic arrivals; with them only tasks 1..vis_cap,
 //     because an agent is never sent to a task that is not visible yet (:578-584) and visible <= cap (:567).  At the
 //     reference's constants (cap 100) that is 2 lane chunks of a 100A/500T instance; the other 400 tasks stay as they were
@@ -24,8 +23,7 @@
 //
 // Registers hold what every call of task_update / agent_update reads on every lane (54 VGPRs of state for <2,2,5>); what a step
 // reads or updates ONCE, by index, sits in LDS (FL below): the routes int32[A][route_cap], the live tasks' location / duration /
-// ordered member ids / len(abandoned_agent), the agents' travel_dist and max(arrival_time) (ds_add_f64 / ds_max_f64 by the
-// agent's own lane).  About 9 KB per env at 100A/500T; after the loop the head of the same bytes holds the terminal metrics'
+// ordered member ids / len(abandoned_agent), the agents' travel_dist (ds_add_f64 by the agent's own lane) and max(arrival_time).  About 9 KB per env at 100A/500T; after the loop the head of the same bytes holds the terminal metrics'
 // serial-sum inputs (f64[T] + f64[A]).  time_start is written once per task to the handle's HBM scratch and read back at the end.
 
 __device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -52,7 +50,7 @@ __host__ __device__ inline uint32_t replay_fast_lds_bytes(int A, int T, int rout
 }
 
 #ifndef DCM_REPLAY_WAVES
-#define DCM_REPLAY_WAVES 1      // minimum waves per SIMD asked of the compiler for k_replay_fast
+#define DCM_REPLAY_WAVES 1      // minimum waves per SIMD asked of the compiler for k_replay_fast (155 VGPRs = three on its own; asking for four spills: slower)
 #endif
 
 template <int NAC, int NTL, int CMR, bool REACTIVE>
@@ -310,6 +308,9 @@ __global__ __launch_bounds__(WAVE, DCM_REPLAY_WAVES) void k_replay_fast(int A, i
                 // for its own agent, lane l's result is the one that counts
                 const int len_l = hl[i] >> 16, head_l = hl[i] & 0xFFFF;
                 const bool pop_l = !(len_l < 0 || head_l >= len_l) && !(REACTIVE && nxt[i] > visible);
+                // (the entry behind the cursor, for the pop below: requested now, a whole distance chain before it is used)
+                const int h1_l = head_l + 1;
+                const int up_l = lroute[(i * WAVE + lane < A ? i * WAVE + lane : 0) * route_cap + (h1_l < route_cap ? h1_l : 0)];
                 const int action = rli(pop_l ? nxt[i] : 0, l);
                 const bool popped = (__ballot(pop_l) >> l) & 1ull;
                 if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
@@ -359,18 +360,13 @@ __global__ __launch_bounds__(WAVE, DCM_REPLAY_WAVES) void k_replay_fast(int A, i
                 // offer 0: a member released by its task finishing before it arrived re-decides early, so the arrival list is not
                 // monotone in replays with surplus visitors; :286 takes the max over the whole list)
                 __hip_atomic_fetch_add(&ltd[i * WAVE + lane], me ? d : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                {
-                    const double mxv = lamx[i * WAVE + lane];
-                    lamx[i * WAVE + lane] = (me && arrival_l > mxv) ? arrival_l : mxv;
-                }
+                __hip_atomic_fetch_max(&lamx[i * WAVE + lane], me ? arrival_l : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (arrivals are >= 0)
                 arr[i] = me ? arrival_l : arr[i];
                 ax[i] = me ? tx_ : ax[i]; ay[i] = me ? ty_ : ay[i];          // :320
                 cur[i] = me ? k : cur[i];                                    // :314
                 ai[i] = me ? ((ai[i] & ~A_MEMBER) | (action == 0 ? A_INDEPOT : 0u) | (joined ? A_MEMBER : 0u)) : ai[i];
                 if (popped) {                                                // :585 pop(0): the cursor moves on, the next entry is staged
-                    const int own = i * WAVE + lane < A ? i * WAVE + lane : 0;      // (every lane for its own agent; lane l's counts)
-                    const int h1 = head_l + 1;
-                    const int up = h1 < len_l ? lroute[own * route_cap + (h1 < route_cap ? h1 : 0)] : 0;
+                    const int up = h1_l < len_l ? up_l : 0;
                     hl[i] = me ? hl[i] + 1 : hl[i];
                     nxt[i] = me ? up : nxt[i];
                     if constexpr (REACTIVE) { const double q = Rep::rearm_quantum(up, P.vis_batch, P.vis_period); rq[i] = me ? q : rq[i]; }
