@@ -316,7 +316,13 @@ struct Sim {
     static_assert(MC + 1 < 20, "dirty mask: bits 1..MC are the arrival rows, 20 / 21 the ids / abandonment counts");
     static constexpr uint32_t DIRTY_TIMES = 1u, DIRTY_ROWS = ((1u << MC) - 1u) << 1, DIRTY_IDS = 1u << 20, DIRTY_NAB = 1u << 21,
                               DIRTY_ALL = DIRTY_TIMES | DIRTY_ROWS | DIRTY_IDS | DIRTY_NAB;
+    static constexpr uint32_t DIRTY_TASK_SHIFT = 22;   // bits 22..31: the joined task (T <= 1023), valid while IDS is set and NAB is not
+    static_assert(DCM_MAX_TASKS < (1 << (32 - 22)), "the joined task must fit the dirty word");
     __device__ __forceinline__ uint32_t* dirty() const { return (uint32_t*)(base + aux_off() + 24); }
+    // second tracking word (lockstep kernels): bits 24..31 = how many tasks became feasible in this step, bits 0..23 = the sum of
+    // their ids -- i.e. THE task when the count is 1 (the common case), so that the write-back can send its 64-byte pieces of
+    // time_start / time_finish instead of the two sections
+    __device__ __forceinline__ uint32_t* dirty2() const { return (uint32_t*)(base + aux_off() + 28); }
     __device__ __forceinline__ void task_update(const HdrRegs& h, const KP& P, int lane, int only = -1, bool track = false) const {
         const double now = h.now, mwt = P.mwt;
         const int T_ = T(), PT_ = PT();
@@ -345,7 +351,7 @@ struct Sim {
             // built inside this rare divergent branch.
             const bool any_drop = !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
             if (!feas0) {
-                if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; if (track) atomicOr(dirty(), DIRTY_TIMES); }  // :256-258
+                if (ok) { ts()[t] = mx; tf()[t] = mx + dur; info |= T_FEAS; if (track) { atomicOr(dirty(), DIRTY_TIMES); atomicAdd(dirty2(), (1u << 24) | (uint32_t)t); } }  // :256-258
                 int nn = n;
                 if (any_drop) {  // rare: compact the surviving members in order
                     uint32_t spread = 0, q1 = 0;
@@ -1071,7 +1077,9 @@ struct Sim {
                 // the scalar unit, and the store does not wait for the sqrt chain of the other members)
 #pragma unroll
                 for (int i = 0; i < NAW; i++) if (i * WAVE + lane == m) marr()[pos * PT() + k] = arrv[i];
-                if (track && lane == 0) *dirty() |= (2u << pos) | DIRTY_IDS;
+                // (bits 22..31 of the dirty word: the task that was joined -- one per step -- so that the write-back can send its
+                //  64-byte pieces of the arrival rows / member ids instead of the sections)
+                if (track && lane == 0) *dirty() = (*dirty() & ((1u << DIRTY_TASK_SHIFT) - 1u)) | (2u << pos) | DIRTY_IDS | ((uint32_t)k << DIRTY_TASK_SHIFT);
             }
             if (lane == 0) { store_ids(k, ids); tinfo()[k] = (info & ~0x00FF0000u) | ((uint32_t)n << 16); }
         }
@@ -1255,7 +1263,7 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
     S.template load_record<false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
-    if (lane == 0) *S.dirty() = 0;
+    if (lane == 0) { *S.dirty() = 0; *S.dirty2() = 0; }
     WSYNC();
     HdrRegs h = load_hdr(smem);
     PHK_MARK(0);                                   // record HBM -> LDS (issue + wait)
@@ -1300,13 +1308,34 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         };
         const uint32_t Tn = (uint32_t)S.PT();
         put(0, L.tb());                                                               // header + agent arrays
-        if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());                 // time_start, time_finish
-        if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
-        else {
+        const uint32_t d2 = uni(*S.dirty2());
+        if ((dm & SimT::DIRTY_TIMES) && !(dm & SimT::DIRTY_NAB) && (d2 >> 24) == 1u) {   // one task became feasible: its pieces of the two arrays
+            const uint32_t bt = d2 & 0xFFFFFFu;
+            for (uint32_t sec : {L.ts(), L.tf()}) {
+                const uint32_t lo = (sec + 8u * bt) & ~63u, end = sec + 8u * Tn;
+                put(lo < sec ? sec : lo, lo + 64u < end ? lo + 64u : end);
+            }
+        } else if (dm & SimT::DIRTY_TIMES) put(L.ts(), L.marr());         // time_start, time_finish
+        // a join (the only thing that dirties arrival rows / member ids without also dirtying the abandonment counts) names its
+        // task: the aligned 64-byte pieces of those sections that hold it go back instead of the 8 T-byte sections
+        const bool one_task = (dm & SimT::DIRTY_IDS) && !(dm & SimT::DIRTY_NAB) && (dm & SimT::DIRTY_ROWS) != SimT::DIRTY_ROWS;
+        if (one_task) {
+            const uint32_t jt = dm >> SimT::DIRTY_TASK_SHIFT;
+            auto piece = [&](uint32_t sec) {
+                const uint32_t lo = (sec + 8u * jt) & ~63u, end = sec + 8u * Tn;
+                put(lo < sec ? sec : lo, lo + 64u < end ? lo + 64u : end);
+            };
 #pragma unroll
-            for (int j = 0; j < MC; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+            for (int j = 0; j < MC; j++) if (dm & (2u << j)) piece(L.marr() + 8u * Tn * j);
+            for (uint32_t w = 0; w < L.idw(); w++) piece(L.mids() + 8u * Tn * w);
+        } else {
+            if ((dm & SimT::DIRTY_ROWS) == SimT::DIRTY_ROWS) put(L.marr(), L.mids());
+            else {
+#pragma unroll
+                for (int j = 0; j < MC; j++) if (dm & (2u << j)) put(L.marr() + 8u * Tn * j, L.marr() + 8u * Tn * (j + 1));
+            }
+            if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
         }
-        if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
         put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());  // status words (+ abandonment counts)
         PHK_MARK(5);                               // write-back (issue)
     }

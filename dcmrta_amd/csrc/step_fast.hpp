@@ -38,7 +38,7 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
     S.template load_record<false>(rec, lane, xy);
     S.set_ablog(ablog, e, BA, BT, lane);
     S.set_retlog(retlog, retcap, e, lane);
-    if (lane == 0) *S.dirty() = 0;
+    if (lane == 0) { *S.dirty() = 0; *S.dirty2() = 0; }
     WSYNC();
     HdrRegs h = load_hdr(smem);
     F f{S, (double*)(smem + SimT::lds_image_bytes(L))};      // (512 bytes of LDS behind the image: the removal path's dummy slots)
