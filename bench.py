@@ -354,7 +354,7 @@ def other_config_shards(dev, visibility, passes=12):
                 trial[S] = dt_ / 4
                 for sb in subs_:
                     sb.env.close()
-            S = min(trial, key=trial.get)
+            S = max(c_ for c_, t_ in trial.items() if t_ <= 1.01 * min(trial.values()))     # (near-ties: the larger stream count)
             dt, n, subs = timed(c, B, eps, S, passes)
             what = f"the per-GPU shard of {cfg['label']} on 8 GPUs" if name != "midsize_70A130T" else \
                 "random-policy rollout at a mid-size shape, 3 episodes per env per pass"
