@@ -89,9 +89,16 @@ struct Lay {
     __host__ __device__ constexpr uint32_t s_tw() const { return 0; }                                    // f64[T]
     __host__ __device__ constexpr uint32_t s_aw() const { return 8 * T; }                                // f64[A]
     __host__ __device__ constexpr uint32_t s_absort() const { return align16(8 * T + 8 * A); }           // u16[A][AB_CAP]
-    __host__ __device__ constexpr uint32_t s_tmx() const { return align16(s_absort() + 2 * AB_CAP * A); }  // f64[T]
+    // f64[A][list_cap]: every agent's member terms in ascending task order (kernels that gather them, see Sim::compute_waits), or
+    // f64[T]: every task's latest arrival (the others); the replay kernels keep u32[2 T] here
+    __host__ __device__ constexpr uint32_t s_terms() const { return align16(s_absort() + 2 * AB_CAP * A); }
+    // tasks that list an agent at the end of an episode, beyond which the per-agent pass walks the lists the slow way: ~ T x 3 / A on
+    // average; 14 keeps the scratch of the one-chunk training shape (20A/50T) small enough for 16 workgroups per CU
+    __host__ __device__ constexpr uint32_t list_cap() const { return T <= 64 ? 14u : 32u; }
     __host__ __device__ constexpr uint32_t twords() const { return (uint32_t)(T + 63) / 64; }
-    __host__ __device__ constexpr uint32_t s_amask() const { return s_tmx() + 8 * T; }                   // u64[A][twords]
+    __host__ __device__ constexpr uint32_t s_amask() const {                                            // u64[A][twords]
+        return s_terms() + (8u * (uint32_t)A * list_cap() > 8u * (uint32_t)T ? 8u * (uint32_t)A * list_cap() : 8u * (uint32_t)T);
+    }
     __host__ __device__ constexpr uint32_t scratch_bytes() const { return align16(s_amask() + 8 * A * twords()); }
     __host__ __device__ constexpr uint32_t lds_bytes() const { return lds_rec() + scratch_bytes(); }     // record + scratch in LDS
 };

@@ -100,6 +100,7 @@ struct Sim {
     unsigned char* base;  // record base (LDS in the env kernels)
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
     double* gm = nullptr; // MG: the marr section of this env's HBM record
+    bool lists = false;   // terminal metrics: gather every agent's member terms into its list (kernels that keep `scr` in LDS)
     static constexpr uint32_t MSH = MG ? 8u * (uint32_t)MC * (uint32_t)CT : 0u;   // = Lay::mids() - Lay::marr()
     // Exact multi-chunk shapes (50A/200T, 100A/500T): the task coordinates -- read-only instance data that only the task's own
     // lane and, for the chosen task, the whole wave ever read -- live in two registers per lane chunk (struct XY, owned by the
@@ -185,7 +186,7 @@ struct Sim {
     __device__ __forceinline__ double* tw() const { return (double*)(scr + L().s_tw()); }
     __device__ __forceinline__ double* aw() const { return (double*)(scr + L().s_aw()); }
     __device__ __forceinline__ uint16_t* absort() const { return (uint16_t*)(scr + L().s_absort()); }
-    __device__ __forceinline__ double* tmx() const { return (double*)(scr + L().s_tmx()); }
+    __device__ __forceinline__ double* terms() const { return (double*)(scr + L().s_terms()); }
     __device__ __forceinline__ unsigned long long* amask() const { return (unsigned long long*)(scr + L().s_amask()); }
     // this env's rows of the abandonment side table (pointer stashed in LDS by the kernel prologue: no SGPRs held)
     __device__ __forceinline__ uint16_t* ablog() const { return *(uint16_t* const*)(base + aux_off()); }
@@ -478,12 +479,28 @@ struct Sim {
     // ------------------------------------------------------------------------------ terminal
     // calculate_waiting_time (env/task_env.py:344-364) into LDS scratch tw[T], aw[A].
     // Returns true when a per-(agent, task) abandonment counter saturated (DCM_FLAG_WAIT_ORDER; the only inexact case).
+    //
+    // The per-task sums are one lane pass.  The per-agent sums (:358-364) must be accumulated in the reference's order -- tasks
+    // ascending; for each task first the member term, then +max_waiting_time once per entry of the agent in that task's
+    // abandoned_agent list -- a serial fp64 chain per agent.  The walking code does that literally: per agent a bitmask of the
+    // tasks that list it, the agent looked up in each of them (status word, id word, arrival slot, the task's latest arrival: a
+    // dependent chain of LDS round trips per task), merged with its abandonment entries sorted in place.  With `lists` (kernels
+    // whose scratch is in LDS) finding the terms is taken out of the serial part: a second lane pass over the TASKS writes every
+    // member's term to its place in the agent's list (place = the number of lower tasks that list the agent), the agent's
+    // abandonment entries (its row of the side table, requested from HBM before the first pass) are sorted in registers, and the
+    // agent lane only reads its list front to back and adds: 10.0 -> 6.3 us per episode end of a 20A/50T wave -- and the wave that
+    // ends an episode is the slowest wave of a lockstep launch.  An agent listed by more than list_cap tasks or with more than
+    // eight abandonments takes the walking code.
     __device__ bool compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A(), PT_ = PT();
         const int TW = (int)L().twords();
+        const int LC = (int)L().list_cap();
+        const bool gather = uni((uint32_t)lists) != 0u && A_ <= WAVE;   // (wave-uniform; the by-value Sim of the out-of-line call arrives in VGPRs)
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
+        uint4 row{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};       // this lane's agent: its first eight abandonment entries
+        if (gather && lane < A_) row = *(const uint4*)(ablog() + lane * AB_CAP);
         for (int i = lane; i < A_ * TW; i += WAVE) amask()[i] = 0ull;         // per agent: bitmask of the tasks listing it
         WSYNC();
         for_tasks(lane, [&](int t) {
@@ -518,77 +535,157 @@ struct Sim {
                 }
             }
             tw()[t] = s + ab;                                                // :351-357
-            tmx()[t] = mx;                                                   // np.max(arrival), reused per agent below
+            if (!gather) terms()[t] = mx;                                    // np.max(arrival), reused per agent by the walking code
             const Ids ids = load_ids(t);
             for (int j = 0; j < n; j++)                                      // transpose members -> per-agent task set
                 atomicOr(&amask()[(int)ids.byte(j) * TW + (t >> 6)], 1ull << (t & 63));
         });
+        WSYNC();
+        // the member term of agent a in task tm (:360 / :362), looked up
+        auto member_term = [&](int a, int tm) {
+            const uint32_t info = tinfo()[tm];
+            const int n = (info >> 16) & 0xFF;
+            const int pos = load_ids(tm).find((uint32_t)a, n);
+            const double mine = marr()[pos * PT_ + tm];
+            double mx;                                                       // np.max(arrival) :350
+            if (gather) {                                                    // (the lists occupy the scratch the first pass would keep it in)
+                mx = marr()[tm];
+                for (int j = 1; j < MC; j++) mx = nanmax2(mx, marr()[j * PT_ + tm]);
+            } else mx = terms()[tm];
+            const double wv = now - mine;
+            return (info & T_FEAS) ? (mx - mine) : ((wv > 0.) ? wv : 0.);
+        };
+        bool walk = lane < A_;                                               // this lane's agent still needs the walking code
+        if (gather) {
+            // every member's term to its place in the agent's list
+            for_tasks(lane, [&](int t) {
+                const uint32_t info = tinfo()[t];
+                const int n = (info >> 16) & 0xFF;
+                const bool feas = info & T_FEAS;
+                double av[MC];
+#pragma unroll
+                for (int j = 0; j < MC; j++) av[j] = marr()[j * PT_ + t];
+                double mx = av[0];
+#pragma unroll
+                for (int j = 1; j < MC; j++) mx = nanmax2(mx, av[j]);
+                const Ids ids = load_ids(t);
+                const int w = t >> 6;
+                const uint64_t below = (1ull << (t & 63)) - 1ull;
+#pragma unroll
+                for (int j = 0; j < MC; j++) {
+                    if (j < n) {
+                        const int a = (int)ids.byte(j);
+                        int place = __popcll(amask()[a * TW + w] & below);
+                        for (int w2 = 0; w2 < w; w2++) place += __popcll(amask()[a * TW + w2]);
+                        const double wv = now - av[j];
+                        if (place < LC) terms()[a * LC + place] = feas ? (mx - av[j]) : ((wv > 0.) ? wv : 0.);
+                    }
+                }
+            });
+            WSYNC();
+            if (lane < A_) {
+                const int a = lane;
+                const uint32_t nab = ainfo()[a] >> 16;
+                int cnt = 0;
+                for (int w = 0; w < TW; w++) cnt += __popcll(amask()[a * TW + w]);
+                if (cnt <= LC && nab <= 8u) {
+                    walk = false;
+                    // the abandonment entries, sorted by task id in registers (Batcher's network for eight; unused ones 0xFFFF sort last)
+                    uint32_t e[8] = {row.x & 0xFFFFu, row.x >> 16, row.y & 0xFFFFu, row.y >> 16, row.z & 0xFFFFu, row.z >> 16, row.w & 0xFFFFu, row.w >> 16};
+#pragma unroll
+                    for (int k = 0; k < 8; k++) e[k] = ((uint32_t)k < nab) ? e[k] : 0xFFFFu;
+                    auto cx = [&](int i, int j) { const uint32_t lo = e[i] < e[j] ? e[i] : e[j], hi = e[i] < e[j] ? e[j] : e[i]; e[i] = lo; e[j] = hi; };
+                    cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+                    cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+                    cx(1, 2); cx(5, 6);
+                    cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
+                    cx(2, 4); cx(3, 5);
+                    cx(1, 2); cx(3, 4); cx(5, 6);
+                    auto pop = [&]() {
+#pragma unroll
+                        for (int k = 0; k < 7; k++) e[k] = e[k + 1];
+                        e[7] = 0xFFFFu;
+                    };
+                    // the list front to back, four terms requested at a time; before a task's term the entries of earlier tasks
+                    double s = 0.;
+                    int w = 0;
+                    uint64_t m = amask()[a * TW];
+                    const double* mine = terms() + a * LC;
+                    for (int i0 = 0; i0 < cnt; i0 += 4) {
+                        double v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[k] = mine[(i0 + k < cnt) ? i0 + k : 0];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (i0 + k < cnt) {
+                                while (!m) m = amask()[a * TW + ++w];
+                                const uint32_t tm = (uint32_t)(w * 64 + __ffsll((unsigned long long)m) - 1);
+                                m &= m - 1;
+                                while (e[0] < tm) { s += mwt; pop(); }           // :363-364 of an earlier task
+                                s += v[k];                                       // :360 / :362
+                            }
+                        }
+                    }
+                    while (e[0] != 0xFFFFu) { s += mwt; pop(); }
+                    aw()[a] = s;
+                }
+            }
+        }
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt1 = __builtin_readcyclecounter();
         if (lane == 0) atomicAdd(&g_phase_cycles[12], pt1 - pt0);
 #endif
-        // :358-364 per agent, accumulated in the reference's order: tasks ascending; for each task first the member
-        // term, then +max_waiting_time once per entry of the agent in that task's abandoned_agent list.  The entries
-        // come from the abandonment log (event order), sorted here by task id; entries beyond AB_CAP per episode
-        // (never seen) would be added as count*mwt at the end.  Membership: SWAR byte search in the packed id word.
-        {   // bring this env's rows of the side table (A x 32 B, contiguous) into LDS with one coalesced pass
-            const uint4* src = (const uint4*)ablog();
-            uint4* dst = (uint4*)absort();
-            for (int i = lane; i < A_ * AB_CAP * 2 / 16; i += WAVE) dst[i] = src[i];
-        }
-        WSYNC();
         bool over = false;
-        for (int a = lane; a < A_; a += WAVE) {
-            const uint32_t nab = ainfo()[a] >> 16;
-            const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
-            uint16_t* my = absort() + a * AB_CAP;
-            for (int i = 1; i < nl; i++) {                                   // in-place insertion sort by task id
-                const uint16_t v = my[i];
-                int j = i;
-                while (j > 0 && my[j - 1] > v) { my[j] = my[j - 1]; j--; }
-                my[j] = v;
+        if (!gather || __any(walk)) {
+            // the walking code.  The abandonment entries come from the log (event order), sorted here by task id; entries beyond
+            // AB_CAP per episode (never seen) are in the dense count table.
+            {   // bring this env's rows of the side table (A x 32 B, contiguous) into LDS with one coalesced pass
+                const uint4* src = (const uint4*)ablog();
+                uint4* dst = (uint4*)absort();
+                for (int i = lane; i < A_ * AB_CAP * 2 / 16; i += WAVE) dst[i] = src[i];
             }
-            int p = 0;
-            double s = 0.;
-            // merge, in ascending task id, the tasks that list the agent (member term) with its abandonment entries
-            for (int w = 0; w < TW; w++) {
-                uint64_t m = amask()[a * TW + w];
-                const int wend = (w + 1) * 64;
-                for (;;) {
-                    const int tm = m ? (w * 64 + __ffsll((unsigned long long)m) - 1) : wend;
-                    if (p < nl && (int)my[p] < tm) { s += mwt; p++; continue; }   // :363-364 of an earlier task
-                    if (!m) break;
-                    m &= m - 1;
-                    const uint32_t info = tinfo()[tm];
-                    const int n = (info >> 16) & 0xFF;
-                    const int pos = load_ids(tm).find((uint32_t)a, n);
-                    const double mine = marr()[pos * PT_ + tm];
-                    const double wv = now - mine;
-                    s += (info & T_FEAS) ? (tmx()[tm] - mine) : ((wv > 0.) ? wv : 0.);   // :360 / :362
+            WSYNC();
+            for (int a = lane; a < A_; a += WAVE) {
+                if (gather && !walk) continue;
+                const uint32_t nab = ainfo()[a] >> 16;
+                const int nl = nab < (uint32_t)AB_CAP ? (int)nab : AB_CAP;
+                uint16_t* my = absort() + a * AB_CAP;
+                for (int i = 1; i < nl; i++) {                               // in-place insertion sort by task id
+                    const uint16_t v = my[i];
+                    int j = i;
+                    while (j > 0 && my[j - 1] > v) { my[j] = my[j - 1]; j--; }
+                    my[j] = v;
                 }
-            }
-            if (nab > (uint32_t)AB_CAP) {
-                // the log overflowed: redo this agent from the dense count table, tasks ascending, member term first and then
-                // one +max_waiting_time per abandonment by that task (:358-364), exact for any number of abandonments
-                const uint16_t* cnt = (const uint16_t*)abcnt() + a * T_;   // abandonments beyond the first AB_CAP (those are in `my`, sorted)
-                s = 0.;
-                int q = 0;
-                for (int t = 0; t < T_; t++) {
-                    if ((amask()[a * TW + (t >> 6)] >> (t & 63)) & 1ull) {
-                        const uint32_t info = tinfo()[t];
-                        const int n = (info >> 16) & 0xFF;
-                        const int pos = load_ids(t).find((uint32_t)a, n);
-                        const double mine = marr()[pos * PT_ + t];
-                        const double wv = now - mine;
-                        s += (info & T_FEAS) ? (tmx()[t] - mine) : ((wv > 0.) ? wv : 0.);
+                double s = 0.;
+                if (nab <= (uint32_t)AB_CAP) {
+                    // merge, in ascending task id, the tasks that list the agent (member term) with its abandonment entries
+                    int p = 0;
+                    for (int w = 0; w < TW; w++) {
+                        uint64_t m = amask()[a * TW + w];
+                        const int wend = (w + 1) * 64;
+                        for (;;) {
+                            const int tm = m ? (w * 64 + __ffsll((unsigned long long)m) - 1) : wend;
+                            if (p < nl && (int)my[p] < tm) { s += mwt; p++; continue; }   // :363-364 of an earlier task
+                            if (!m) break;
+                            m &= m - 1;
+                            s += member_term(a, tm);
+                        }
                     }
-                    int c = cnt[t];
-                    over = over || c == 65535;                                // saturated counter: the only inexact case left
-                    while (q < nl && my[q] == (uint16_t)t) { c++; q++; }
-                    for (int k = 0; k < c; k++) s += mwt;
+                } else {
+                    // the log overflowed: this agent from the dense count table, tasks ascending, member term first and then
+                    // one +max_waiting_time per abandonment by that task (:358-364), exact for any number of abandonments
+                    const uint16_t* cnt16 = (const uint16_t*)abcnt() + a * T_;   // abandonments beyond the first AB_CAP (those are in `my`, sorted)
+                    int q = 0;
+                    for (int t = 0; t < T_; t++) {
+                        if ((amask()[a * TW + (t >> 6)] >> (t & 63)) & 1ull) s += member_term(a, t);
+                        int c = cnt16[t];
+                        over = over || c == 65535;                            // saturated counter: the only inexact case left
+                        while (q < nl && my[q] == (uint16_t)t) { c++; q++; }
+                        for (int k = 0; k < c; k++) s += mwt;
+                    }
                 }
+                aw()[a] = s;
             }
-            aw()[a] = s;
         }
 #ifdef DCM_PROFILE_PHASES
         if (lane == 0) atomicAdd(&g_phase_cycles[13], __builtin_readcyclecounter() - pt1);
@@ -1404,6 +1501,7 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
     using AMask = typename SimT::AMask;
     const Lay L = S.L();
     S.scr = SimT::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
+    S.lists = SimT::SCR_IN_LDS;
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     S.gm = (double*)(rec + L.marr());
@@ -1847,7 +1945,9 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     if (quiet_ok && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
         mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
 #define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), env->kp, \
+    hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env),                                                           \
+                       (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u + (step_scratch_in_lds<CA, CT>() ? env->L.scratch_bytes() : 0u), \
+                       (hipStream_t)stream, DIMS(env), env->kp,                                                            \
                        env->state, actions, agents_out, tasks_out, mask_out, leader_out, active_out, env->summary, env->ablog,  \
                        env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
         const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;

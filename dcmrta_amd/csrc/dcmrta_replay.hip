@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WAVE) void k_replay(int A_, int T_, int PA, int PT,
     Rep R{A, T, MR, smem, RLay{A, T, MR}, (const double*)(rec + EL.tx()), (const double*)(rec + EL.ty()),
           (const double*)(rec + EL.tdur()), (double*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tw()),
           (uint16_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_absort()),
-          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_tmx()), SLDS ? (double*)(smem + RLay{A, T, MR}.state())
+          (uint32_t*)(gscr + (size_t)e * EL.scratch_bytes() + EL.s_terms()), SLDS ? (double*)(smem + RLay{A, T, MR}.state())
                : (double*)((unsigned char*)member_arrivals + (size_t)e * replay_scratch_bytes(A, T, MR))};
     const Hdr* gh = (const Hdr*)rec;
     const double depot_x = uni(gh->depot_x), depot_y = uni(gh->depot_y);

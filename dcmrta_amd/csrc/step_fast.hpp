@@ -15,6 +15,12 @@
 #define DCM_STEP_WAVES 4       // minimum waves per SIMD asked of the compiler for k_step_fast
 #endif
 
+// The terminal metrics' scratch (calculate_waiting_time: 1.8 KB at 20A/50T) sits in LDS behind the dummy slots when 16 workgroups
+// per CU -- all that the kernel's VGPRs allow -- still fit: the env whose episode ends in a launch is that launch's slowest wave,
+// and with the scratch in HBM every write -> WSYNC -> read phase of the metrics is a global-memory round trip.
+template <int CA, int CT>
+constexpr bool step_scratch_in_lds() { return Lay{CA, CT}.lds_bytes() + 512u <= 10240u; }
+
 template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, const int32_t* actions,
                                                    float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
@@ -29,7 +35,8 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
     using AMask = typename SimT::AMask;
     SimT S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
-    S.scr = gscr + (size_t)e * L.scratch_bytes();
+    S.scr = step_scratch_in_lds<CA, CT>() ? smem + SimT::lds_image_bytes(L) + 512u : gscr + (size_t)e * L.scratch_bytes();
+    S.lists = step_scratch_in_lds<CA, CT>();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     double* row = summary + (size_t)e * 8;
