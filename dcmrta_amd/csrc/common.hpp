@@ -92,9 +92,10 @@ struct Lay {
     // f64[A][list_cap]: every agent's member terms in ascending task order (kernels that gather them, see Sim::compute_waits), or
     // f64[T]: every task's latest arrival (the others); the replay kernels keep u32[2 T] here
     __host__ __device__ constexpr uint32_t s_terms() const { return align16(s_absort() + 2 * AB_CAP * A); }
-    // tasks that list an agent at the end of an episode, beyond which the per-agent pass walks the lists the slow way: ~ T x 3 / A on
-    // average; 14 keeps the scratch of the one-chunk training shape (20A/50T) small enough for 16 workgroups per CU
-    __host__ __device__ constexpr uint32_t list_cap() const { return T <= 64 ? 14u : 32u; }
+    // entries of an agent's list (the tasks that list it at the end of an episode: ~ T x 3 / A on average), beyond which the
+    // per-agent pass walks the tasks the slow way.  14 keeps the scratch of the one-chunk training shape (20A/50T) small enough for
+    // 16 workgroups per CU; layouts with more than one task chunk never have their scratch in LDS and keep no lists
+    __host__ __device__ constexpr uint32_t list_cap() const { return T <= 64 ? 14u : 0u; }
     __host__ __device__ constexpr uint32_t twords() const { return (uint32_t)(T + 63) / 64; }
     __host__ __device__ constexpr uint32_t s_amask() const {                                            // u64[A][twords]
         return s_terms() + (8u * (uint32_t)A * list_cap() > 8u * (uint32_t)T ? 8u * (uint32_t)A * list_cap() : 8u * (uint32_t)T);
@@ -164,6 +165,15 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     } while (0)
 
 // ---------------------------------------------------------------------------------- uniform helpers
+// does a generic pointer point into LDS?  (the aperture test on its high half; false in the host pass, which never calls it)
+__device__ __forceinline__ bool in_lds(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)p);
+#else
+    (void)p;
+    return false;
+#endif
+}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uni(uint64_t v) {

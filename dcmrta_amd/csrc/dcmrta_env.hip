@@ -100,7 +100,6 @@ struct Sim {
     unsigned char* base;  // record base (LDS in the env kernels)
     unsigned char* scr;   // terminal-metrics scratch (LDS behind the record, or this env's slice of the HBM scratch)
     double* gm = nullptr; // MG: the marr section of this env's HBM record
-    bool lists = false;   // terminal metrics: gather every agent's member terms into its list (kernels that keep `scr` in LDS)
     static constexpr uint32_t MSH = MG ? 8u * (uint32_t)MC * (uint32_t)CT : 0u;   // = Lay::mids() - Lay::marr()
     // Exact multi-chunk shapes (50A/200T, 100A/500T): the task coordinates -- read-only instance data that only the task's own
     // lane and, for the chosen task, the whole wave ever read -- live in two registers per lane chunk (struct XY, owned by the
@@ -484,18 +483,21 @@ struct Sim {
     // ascending; for each task first the member term, then +max_waiting_time once per entry of the agent in that task's
     // abandoned_agent list -- a serial fp64 chain per agent.  The walking code does that literally: per agent a bitmask of the
     // tasks that list it, the agent looked up in each of them (status word, id word, arrival slot, the task's latest arrival: a
-    // dependent chain of LDS round trips per task), merged with its abandonment entries sorted in place.  With `lists` (kernels
-    // whose scratch is in LDS) finding the terms is taken out of the serial part: a second lane pass over the TASKS writes every
-    // member's term to its place in the agent's list (place = the number of lower tasks that list the agent), the agent's
-    // abandonment entries (its row of the side table, requested from HBM before the first pass) are sorted in registers, and the
-    // agent lane only reads its list front to back and adds: 10.0 -> 6.3 us per episode end of a 20A/50T wave -- and the wave that
-    // ends an episode is the slowest wave of a lockstep launch.  An agent listed by more than list_cap tasks or with more than
-    // eight abandonments takes the walking code.
+    // dependent chain of LDS round trips per task), merged with its abandonment entries sorted in place.
+    // When the scratch is in LDS (the one-chunk kernels) everything but the additions is taken out of the serial part: a second
+    // lane pass over the TASKS writes every member's term to its place in the agent's list (place = the number of lower tasks that
+    // list the agent) together with the number of the agent's abandonment entries that belong to lower tasks (its row of the side
+    // table is requested from HBM before the first pass), and the agent lane reads its list front to back and adds.  Measured on
+    // the wave that ends a 20A/50T episode (s_memrealtime marks): 10.0 -> 6.4 us for the whole terminal call -- and that wave is
+    // the slowest wave of a lockstep launch.  An agent listed by more than list_cap tasks or with more than eight abandonments
+    // takes the walking code.
     __device__ bool compute_waits(double now, double mwt, int lane) const {
         const int T_ = T(), A_ = A(), PT_ = PT();
         const int TW = (int)L().twords();
         const int LC = (int)L().list_cap();
-        const bool gather = uni((uint32_t)lists) != 0u && A_ <= WAVE;   // (wave-uniform; the by-value Sim of the out-of-line call arrives in VGPRs)
+        // (compiled only into the simulators whose scratch can be in LDS: the code's mere presence in the out-of-line function costs the
+        //  general k_step of the mid-size class 2 us per launch -- registers it clobbers are registers the caller cannot keep live)
+        const bool gather = SCR_IN_LDS && uni((uint32_t)in_lds(scr)) != 0u && A_ <= WAVE && LC >= 1 && LC <= 16;
 #ifdef DCM_PROFILE_PHASES
         const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
@@ -540,6 +542,13 @@ struct Sim {
             for (int j = 0; j < n; j++)                                      // transpose members -> per-agent task set
                 atomicOr(&amask()[(int)ids.byte(j) * TW + (t >> 6)], 1ull << (t & 63));
         });
+        uint32_t nab0 = 0;                                                   // this lane's agent: its number of abandonments
+        if (gather && lane < A_) {
+            // the agent's entries where the task lanes of the second pass find them; entries it does not have become 0xFFFF
+            nab0 = ainfo()[lane] >> 16;
+            auto pad = [&](uint32_t v, uint32_t k) { return (k < nab0 ? (v & 0xFFFFu) : 0xFFFFu) | (k + 1u < nab0 ? (v & 0xFFFF0000u) : 0xFFFF0000u); };
+            *(uint4*)(absort() + lane * AB_CAP) = uint4{pad(row.x, 0u), pad(row.y, 2u), pad(row.z, 4u), pad(row.w, 6u)};
+        }
         WSYNC();
         // the member term of agent a in task tm (:360 / :362), looked up
         auto member_term = [&](int a, int tm) {
@@ -557,76 +566,81 @@ struct Sim {
         };
         bool walk = lane < A_;                                               // this lane's agent still needs the walking code
         if (gather) {
-            // every member's term to its place in the agent's list
+            // (LDS-typed pointers: this function is out of line and sees `base` / `scr` as generic pointers -- flat instructions,
+            //  64-bit addresses; here both are known to be LDS)
+            typedef __attribute__((address_space(3))) unsigned char* lds_p;
+            const lds_p lscr = (lds_p)scr, limg = (lds_p)base;
+            auto* const l_amask = (__attribute__((address_space(3))) unsigned long long*)(lscr + L().s_amask());
+            auto* const l_terms = (__attribute__((address_space(3))) double*)(lscr + L().s_terms());
+            const lds_p l_rows = lscr + L().s_absort();                      // per agent 32 B: eight entries, sixteen count bytes
+            auto* const l_marr = (__attribute__((address_space(3))) const double*)(limg + L().marr() - MSH);
+            auto* const l_tinfo = (__attribute__((address_space(3))) const uint32_t*)(limg + L().tinfo() - MSH);
+            // every member's term to its place in the agent's list, and with it the number of the agent's abandonment entries that
+            // belong to lower tasks (the +max_waiting_time additions that precede the term)
             for_tasks(lane, [&](int t) {
-                const uint32_t info = tinfo()[t];
+                const uint32_t info = l_tinfo[t];
                 const int n = (info >> 16) & 0xFF;
                 const bool feas = info & T_FEAS;
                 double av[MC];
 #pragma unroll
-                for (int j = 0; j < MC; j++) av[j] = marr()[j * PT_ + t];
+                for (int j = 0; j < MC; j++) av[j] = l_marr[j * PT_ + t];
                 double mx = av[0];
 #pragma unroll
                 for (int j = 1; j < MC; j++) mx = nanmax2(mx, av[j]);
                 const Ids ids = load_ids(t);
                 const int w = t >> 6;
                 const uint64_t below = (1ull << (t & 63)) - 1ull;
+                const uint32_t tt = (uint32_t)t;
 #pragma unroll
                 for (int j = 0; j < MC; j++) {
                     if (j < n) {
                         const int a = (int)ids.byte(j);
-                        int place = __popcll(amask()[a * TW + w] & below);
-                        for (int w2 = 0; w2 < w; w2++) place += __popcll(amask()[a * TW + w2]);
+                        int place = __popcll(l_amask[a * TW + w] & below);
+                        for (int w2 = 0; w2 < w; w2++) place += __popcll(l_amask[a * TW + w2]);
+                        auto* const ev = (const __attribute__((address_space(3))) uint32_t*)(l_rows + a * (2 * AB_CAP));   // (0xFFFF: no entry)
+                        const uint32_t e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3];
+                        const uint32_t before = (uint32_t)((e0 & 0xFFFFu) < tt) + (uint32_t)((e0 >> 16) < tt) + (uint32_t)((e1 & 0xFFFFu) < tt) +
+                                                (uint32_t)((e1 >> 16) < tt) + (uint32_t)((e2 & 0xFFFFu) < tt) + (uint32_t)((e2 >> 16) < tt) +
+                                                (uint32_t)((e3 & 0xFFFFu) < tt) + (uint32_t)((e3 >> 16) < tt);
                         const double wv = now - av[j];
-                        if (place < LC) terms()[a * LC + place] = feas ? (mx - av[j]) : ((wv > 0.) ? wv : 0.);
+                        if (place < LC) {
+                            l_terms[a * LC + place] = feas ? (mx - av[j]) : ((wv > 0.) ? wv : 0.);
+                            (l_rows + a * (2 * AB_CAP) + 16)[place] = (unsigned char)before;
+                        }
                     }
                 }
             });
             WSYNC();
             if (lane < A_) {
                 const int a = lane;
-                const uint32_t nab = ainfo()[a] >> 16;
                 int cnt = 0;
-                for (int w = 0; w < TW; w++) cnt += __popcll(amask()[a * TW + w]);
-                if (cnt <= LC && nab <= 8u) {
+                for (int w = 0; w < TW; w++) cnt += __popcll(l_amask[a * TW + w]);
+                if (cnt <= LC && nab0 <= 8u) {
                     walk = false;
-                    // the abandonment entries, sorted by task id in registers (Batcher's network for eight; unused ones 0xFFFF sort last)
-                    uint32_t e[8] = {row.x & 0xFFFFu, row.x >> 16, row.y & 0xFFFFu, row.y >> 16, row.z & 0xFFFFu, row.z >> 16, row.w & 0xFFFFu, row.w >> 16};
-#pragma unroll
-                    for (int k = 0; k < 8; k++) e[k] = ((uint32_t)k < nab) ? e[k] : 0xFFFFu;
-                    auto cx = [&](int i, int j) { const uint32_t lo = e[i] < e[j] ? e[i] : e[j], hi = e[i] < e[j] ? e[j] : e[i]; e[i] = lo; e[j] = hi; };
-                    cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
-                    cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
-                    cx(1, 2); cx(5, 6);
-                    cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
-                    cx(2, 4); cx(3, 5);
-                    cx(1, 2); cx(3, 4); cx(5, 6);
-                    auto pop = [&]() {
-#pragma unroll
-                        for (int k = 0; k < 7; k++) e[k] = e[k + 1];
-                        e[7] = 0xFFFFu;
-                    };
-                    // the list front to back, four terms requested at a time; before a task's term the entries of earlier tasks
+                    // the list front to back (four terms requested at a time): before each term the entries of lower tasks that
+                    // have not been added yet (:363-364), then the term (:360 / :362); the remaining entries at the end
+                    auto* const bv = (const __attribute__((address_space(3))) uint32_t*)(l_rows + a * (2 * AB_CAP) + 16);
+                    const uint32_t bw[4] = {bv[0], bv[1], bv[2], bv[3]};
+                    auto* const mine = l_terms + a * LC;
                     double s = 0.;
-                    int w = 0;
-                    uint64_t m = amask()[a * TW];
-                    const double* mine = terms() + a * LC;
-                    for (int i0 = 0; i0 < cnt; i0 += 4) {
-                        double v[4];
+                    int done = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v[k] = mine[(i0 + k < cnt) ? i0 + k : 0];
+                    for (int c = 0; c < 4; c++) {
+                        if (4 * c < cnt) {
+                            double v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            if (i0 + k < cnt) {
-                                while (!m) m = amask()[a * TW + ++w];
-                                const uint32_t tm = (uint32_t)(w * 64 + __ffsll((unsigned long long)m) - 1);
-                                m &= m - 1;
-                                while (e[0] < tm) { s += mwt; pop(); }           // :363-364 of an earlier task
-                                s += v[k];                                       // :360 / :362
+                            for (int k = 0; k < 4; k++) v[k] = mine[(4 * c + k < cnt) ? 4 * c + k : 0];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (4 * c + k < cnt) {
+                                    const int before = (int)((bw[c] >> (8 * k)) & 0xFFu);
+                                    for (; done < before; done++) s += mwt;
+                                    s += v[k];
+                                }
                             }
                         }
                     }
-                    while (e[0] != 0xFFFFu) { s += mwt; pop(); }
+                    for (; done < (int)nab0; done++) s += mwt;
                     aw()[a] = s;
                 }
             }
@@ -1501,7 +1515,6 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
     using AMask = typename SimT::AMask;
     const Lay L = S.L();
     S.scr = SimT::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
-    S.lists = SimT::SCR_IN_LDS;
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     S.gm = (double*)(rec + L.marr());

@@ -441,7 +441,6 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     SimT S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
     S.scr = SimT::SCR_IN_LDS ? smem + L.lds_rec() : gscr + (size_t)e * L.scratch_bytes();
-    S.lists = SimT::SCR_IN_LDS;
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     typename SimT::XY xy;

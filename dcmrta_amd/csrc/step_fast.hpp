@@ -36,7 +36,6 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
     SimT S{eA, eT, PA, PT, smem, nullptr};
     const Lay L = S.L();
     S.scr = step_scratch_in_lds<CA, CT>() ? smem + SimT::lds_image_bytes(L) + 512u : gscr + (size_t)e * L.scratch_bytes();
-    S.lists = step_scratch_in_lds<CA, CT>();
     const int BA = S.BA(A), BT = S.BT(T);
     unsigned char* rec = state + (size_t)e * L.rec_bytes();
     double* row = summary + (size_t)e * 8;
@@ -55,55 +54,9 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
     constexpr uint32_t ERR = DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE;
     const bool was_active = !(h.flags & DCM_FLAG_DONE);
     PH_DECL;
+    // the rest of the launch: registers -> image, header, write-back, the next decision's observation
+    auto finish = [&](bool regs) __attribute__((always_inline)) {
     if (was_active) {
-        f.load_consts(r);
-        f.reload(r);
-        const uint64_t k1 = key1(h.seed, h.d);
-        // an action the device policy could have taken?  (env/task_env.py:192-200 + worker.py:58-61: an unmasked task; the depot
-        // is simulated the same way whether or not it is masked: the whole co-located group returns)
-        bool plain = act_in == 0;
-        if (act_in >= 1 && act_in <= S.T()) {
-            const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)r.ti, act_in - 1);
-            plain = !(ik & T_FEAS) && (int)(int8_t)((ik >> 8) & 0xFF) > 0;
-        }
-        if (plain) {
-            uint64_t gm;
-            const int leader = f.pick_leader(r, h, k1, gm);
-            if (leader < 0) h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE;     // unreachable: groups are never empty
-            else {
-                const int rlen = f.apply(r, h, P, lane, k1, gm, leader, act_in);
-                h.d += 1;
-                regs = true;
-                if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
-                    if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group
-                    else if (!f.next_event(r, h, P, lane)) {                      // worker.py:85 -> :45
-                        f.flush(r);
-                        regs = false;
-                        S.advance(h, P, lane, row PH_PASS, false, true);
-                    }
-                }
-            }
-        } else {
-            // masked / out-of-range action: simulated (or refused, DCM_PARAM_STRICT_MASK) by the general code, see apply_and_advance
-            AMask gm;
-            const int leader = S.pick_leader(h, lane, -1, k1, gm, false);
-            if (leader >= 0)
-                S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0,
-                                    false, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true, &xy);
-        }
-        // wave-uniform by construction; tell the compiler so
-        h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
-        h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
-        // DCM_PARAM_AUTO_RESET: the episode has just ended -> start the next one from the loaded instance (see k_step); an episode
-        // only ever ends in the general code, so the LDS image is current here
-        if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) && !(h.flags & ERR) &&
-            (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
-            S.reset_state(h, lane);
-            if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
-            S.advance(h, P, lane, row PH_PASS, false);
-            h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
-            h.empty_passes = uni(h.empty_passes);
-        }
         if (regs) f.flush(r);
         WSYNC();
         store_hdr(h, lane);
@@ -159,6 +112,7 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
             if (dm & SimT::DIRTY_IDS) put(L.mids(), L.tinfo());
             put(L.tinfo(), (dm & SimT::DIRTY_NAB) ? L.mut_bytes() : L.tnab());        // status words (+ abandonment counts)
         }
+    
     }
     // mask + observation of the next decision (worker.py:57-68), fused
     WSYNC();
@@ -197,4 +151,67 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
         leader_out[e] = leader;
         active_out[e] = leader >= 0 ? 1 : 0;
     }
+    };
+    if (was_active) {
+        f.load_consts(r);
+        f.reload(r);
+        const uint64_t k1 = key1(h.seed, h.d);
+        // an action the device policy could have taken?  (env/task_env.py:192-200 + worker.py:58-61: an unmasked task; the depot
+        // is simulated the same way whether or not it is masked: the whole co-located group returns)
+        bool plain = act_in == 0;
+        if (act_in >= 1 && act_in <= S.T()) {
+            const uint32_t ik = (uint32_t)__builtin_amdgcn_readlane((int)r.ti, act_in - 1);
+            plain = !(ik & T_FEAS) && (int)(int8_t)((ik >> 8) & 0xFF) > 0;
+        }
+        bool general = !plain;                     // the step, or the rest of it, needs the general code
+        if (plain) {
+            uint64_t gm;
+            const int leader = f.pick_leader(r, h, k1, gm);
+            if (leader < 0) h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE;     // unreachable: groups are never empty
+            else {
+                const int rlen = f.apply(r, h, P, lane, k1, gm, leader, act_in);
+                h.d += 1;
+                regs = true;
+                if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
+                    if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group
+                    else general = !f.next_event(r, h, P, lane);                  // worker.py:85 -> :45
+                }
+            }
+        }
+        if (uni((uint32_t)general) != 0u) {
+            // The general code -- the end of an episode (+ auto-reset), MAX_TIME, a masked action -- runs to the end of the launch
+            // in a region of its own that the common path never rejoins.  Its out-of-line terminal metrics clobber 96 scalar and 68
+            // vector registers; with one shared tail behind the call the common path's values lived across it and the kernel sat at
+            // its 128-VGPR limit with 40 B of spills, some of them on the common path.  Two tails: 105 VGPRs, no spills of its own.
+            if (plain) {
+                f.flush(r);
+                S.advance(h, P, lane, row PH_PASS, false, true);
+            } else {
+                // masked / out-of-range action: simulated (or refused, DCM_PARAM_STRICT_MASK) by the general code, see apply_and_advance
+                AMask gm;
+                const int leader = S.pick_leader(h, lane, -1, k1, gm, false);
+                if (leader >= 0)
+                    S.apply_and_advance(h, P, lane, leader, gm, act_in, k1, -1, nullptr, row PH_PASS, RouteLog{nullptr, nullptr, nullptr, 0}, 0,
+                                        false, (mode & DCM_PARAM_STRICT_MASK) ? 2 : 1, false, true, &xy);
+            }
+            h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+            h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
+            // DCM_PARAM_AUTO_RESET: the episode has just ended -> start the next one from the loaded instance (see k_step); an episode
+            // only ever ends in the general code, so the LDS image is current here
+            if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) && !(h.flags & ERR) &&
+                (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
+                S.reset_state(h, lane);
+                if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
+                S.advance(h, P, lane, row PH_PASS, false);
+                h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+                h.empty_passes = uni(h.empty_passes);
+            }
+            finish(false);
+            return;
+        }
+        // wave-uniform by construction; tell the compiler so
+        h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+        h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
+    }
+    finish(regs);
 }
