@@ -163,3 +163,47 @@ def test_ragged_argument_errors(gpu_device):
     env.load_routes([[[0] for _ in range(A)] for _ in range(B)])
     with pytest.raises(DcmError):
         env.execute_routes()
+
+
+@pytest.mark.parametrize("mwt", [10.0, 1.0, 0.25])
+def test_terminal_metrics_lists_and_their_fallbacks(gpu_device, mwt):
+    """The per-agent waiting-time sums (env/task_env.py:358-364) in the 20A/50T layout, whose kernels gather every agent's member
+    terms into a list of at most 14 entries and count at most eight of its abandonment entries per task: few agents x many tasks
+    (lists longer than 14), a short max_waiting_time (more than 8, and more than the log's 16, abandonments per agent) and the
+    plain shape in one batch -- persistent kernel (two episodes) and lockstep API, every env bit-equal to the oracle."""
+    import oracle
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    sizes = [(20, 50), (2, 50), (3, 50), (1, 50), (4, 45), (20, 50), (6, 50), (2, 17), (12, 50), (5, 50), (20, 12), (8, 50)]
+    inst = _custom(sizes, 20, 50, seed=11)
+    B = len(sizes)
+    for b, (a, t) in enumerate(sizes):                        # few agents: requirements they can meet, so that tasks finish and list them
+        if a <= 3:
+            inst["req"][b, :] = 1
+        elif a <= 6:
+            inst["req"][b, :] = np.minimum(inst["req"][b, :], 2)
+    seeds = env_seeds(77, 0, B)
+    env = BatchedTaskEnv(B, 20, 50, device=gpu_device, max_waiting_time=mwt).load_instances(**inst)
+    env.reset(seeds, observe=False)
+    steps = env.rollout_random(2).cpu().numpy()
+    fin = H.gpu_final(env)
+    long_lists = many = 0
+    for b, (a, t) in enumerate(sizes):
+        o = _oracle(inst, b, mwt)
+        r1 = o.rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False)
+        o.clear_decisions()
+        r2 = o.rollout(int(seeds[b]), r1["n_steps"], oracle.POLICY_RANDOM, cap_steps=100000, record=False)
+        assert steps[b] == r1["n_steps"] + r2["n_steps"], (b, a, t)
+        H.assert_final_matches(_slice_final(fin[b], a, t), r2, f"env {b} ({a}A/{t}T, mwt {mwt})")
+        long_lists += int(np.sum(r2["n_members"]) > 14 * a)
+        many += int(np.sum(r2["n_abandoned"]) > 8 * a)
+    assert long_lists >= 1                                    # some agent is listed by more than 14 tasks (pigeonhole)
+    if mwt < 1.0:
+        assert many >= 1                                      # some agent was abandoned more than eight times (pigeonhole)
+    # the same batch through the lockstep kernel (k_step_fast), one episode
+    env2 = BatchedTaskEnv(B, 20, 50, device=gpu_device, max_waiting_time=mwt).load_instances(**inst)
+    H.run_lockstep(env2, seeds, lambda b, i, m, l: H.host_random_action(m, int(seeds[b]), i))
+    fin2 = H.gpu_final(env2)
+    for b, (a, t) in enumerate(sizes):
+        ref = _oracle(inst, b, mwt).rollout(int(seeds[b]), 0, oracle.POLICY_RANDOM, cap_steps=100000, record=False)
+        H.assert_final_matches(_slice_final(fin2[b], a, t), ref, f"lockstep env {b} ({a}A/{t}T, mwt {mwt})")
