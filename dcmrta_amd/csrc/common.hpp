@@ -84,8 +84,9 @@ struct Lay {
     __host__ __device__ constexpr uint32_t aux() const { return rec_bytes(); }
     __host__ __device__ constexpr uint32_t lds_rec() const { return rec_bytes() + 48; }
     // Scratch of the terminal metrics (calculate_waiting_time), offsets relative to its own base: behind the record in LDS
-    // for the persistent kernel of the small shapes, a per-env HBM buffer otherwise (an episode ends once in ~120 decisions;
-    // keeping 1.8 KB of LDS per env for it costs k_step 6 of its 27 resident workgroups per CU)
+    // for the one-chunk persistent and lockstep kernels (4 waves per SIMD by their VGPRs: up to 10 KB of LDS per env is free), a
+    // per-env HBM buffer otherwise (an episode ends once in ~120 decisions; in LDS it would cost the general k_step, 7 waves per
+    // SIMD, a quarter of its resident workgroups)
     __host__ __device__ constexpr uint32_t s_tw() const { return 0; }                                    // f64[T]
     __host__ __device__ constexpr uint32_t s_aw() const { return 8 * T; }                                // f64[A]
     __host__ __device__ constexpr uint32_t s_absort() const { return align16(8 * T + 8 * A); }           // u16[A][AB_CAP]

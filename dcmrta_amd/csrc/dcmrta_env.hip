@@ -110,8 +110,9 @@ struct Sim {
     static constexpr bool IRB = (CT > WAVE) && !RS;
     static_assert(!MG || ((CT > WAVE) && !RS), "MG needs an exact multi-chunk shape");
     struct XY { double x[IRB ? NTC : 1], y[IRB ? NTC : 1]; };
-    // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (7.6 KB per env still lets all 4096 envs of the
-    // BASELINE batch be resident); every other kernel trades it for more resident workgroups
+    // the persistent kernel of the one-chunk shapes keeps the scratch in LDS (9.5 KB per env at 20A/50T with the per-agent term
+    // lists, + 512 B of dummy slots: sixteen workgroups fill the CU's 160 KB exactly and all 4096 envs of the BASELINE batch are
+    // resident); every other kernel trades it for more resident workgroups
     static constexpr bool SCR_IN_LDS = (CA != 0 && !RL && Lay{CA, CT}.lds_bytes() <= 10240);   // 16 workgroups per CU still fit
 
     __device__ __forceinline__ int A() const { return EXACT ? CA : rA; }

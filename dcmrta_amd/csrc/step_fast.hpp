@@ -15,7 +15,7 @@
 #define DCM_STEP_WAVES 4       // minimum waves per SIMD asked of the compiler for k_step_fast
 #endif
 
-// The terminal metrics' scratch (calculate_waiting_time: 1.8 KB at 20A/50T) sits in LDS behind the dummy slots when 16 workgroups
+// The terminal metrics' scratch (calculate_waiting_time: 3.6 KB at 20A/50T) sits in LDS behind the dummy slots when 16 workgroups
 // per CU -- all that the kernel's VGPRs allow -- still fit: the env whose episode ends in a launch is that launch's slowest wave,
 // and with the scratch in HBM every write -> WSYNC -> read phase of the metrics is a global-memory round trip.
 template <int CA, int CT>
