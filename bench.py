@@ -178,6 +178,14 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
         ev[i][1].record()
     torch.cuda.synchronize(dev)
     ms = sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+    # what an event pair costs by itself (two marker packets with nothing between them): the part of `median_launch_ms` that is
+    # not the kernel -- rocprofv3's kernel-trace average of the same window is shorter by about this much
+    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+    for a, b in empty:
+        a.record()
+        b.record()
+    torch.cuda.synchronize(dev)
+    bracket_us = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2] * 1e3
     Wb = algorithmic_bytes_per_step(A, T)
     c = load_counters(f"k_step:{B}x{A}A{T}T")
     out = {"kernel": step_kernel_name(A, T), "envs": B, "median_launch_ms": ms, "steps_per_s": B / ms * 1e3, "bound": "hbm",
@@ -186,7 +194,7 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
            "traffic": c.get("hbm_bytes_per_launch") if c else None,
            "traffic_frac": (c["hbm_bytes_per_launch"] / (ms * 1e-3) / HBM_PEAK_BYTES_PER_S) if c and c.get("hbm_bytes_per_launch") else None,
            "counters_source": c.get("source") if c else None,
-           "rocprof_avg_launch_us": c.get("avg_launch_us") if c else None,
+           "rocprof_avg_launch_us": c.get("avg_launch_us") if c else None, "empty_event_pair_us": bracket_us,
            "stale": staleness(c, _lib.build_id()) if c else None}
     env.close()
     return out

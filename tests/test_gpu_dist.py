@@ -170,6 +170,7 @@ def test_default_line_times_the_other_baseline_configs(gpu_device):
     assert 4096 * 3 * 200 < oc["midsize_70A130T"]["steps_per_pass"] < 4096 * 3 * 500   # ~296 decisions per 70A/130T episode
     lk = j["lockstep_kernel"]
     assert lk["kernel"] == "k_step_fast" and 0.2 < lk["frac"] < 1.2 and (lk["traffic_frac"] is None or lk["traffic_frac"] < lk["frac"])
+    assert 0.0 < lk["empty_event_pair_us"] < 0.5 * 1e3 * lk["median_launch_ms"]      # the timing brackets' own cost, reported beside it
     assert j["cpu_baseline"]["value"] > 0 and j["value"] > 1e6
     # bench-size oracle parity of the headline workload and of every shard; each shard with its own roofline and CPU baseline
     assert j["parity"]["envs_checked"] == 4096 and j["parity"]["mismatches"] == 0
