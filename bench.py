@@ -351,6 +351,7 @@ def other_config_shards(dev, visibility, passes=12):
     for name, cfg, B, eps in (("config4_shard", CONFIGS["4"], 8192, 1), ("config5_shard", CONFIGS["5"], 8192, 1), ("midsize_70A130T", mid, 4096, 3)):
         try:
             A, T = cfg["agents"], cfg["tasks"]
+            instances_block(A, T, 0, B)               # the whole shard once; the sub-batches of every trial slice it
             c = dict(cfg, kernel=rollout_kernel_name(A, T) if cfg["kernel"] == "rollout" else replay_kernel_name(A, T, 5, True, visibility[3]),
                      episodes=eps)
             # like the headline workload the shard is cut into sub-batches on separate HIP streams when that pays (a launch lasts as
@@ -382,11 +383,93 @@ def other_config_shards(dev, visibility, passes=12):
                 sb.env.close()
         except Exception as ex:      # (an auxiliary entry must never take the headline line down with it)
             out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        _INST.pop((cfg["agents"], cfg["tasks"]), None)
     try:
         out["config3"] = config3_probe(dev)
     except Exception as ex:
         out["config3"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return out
+
+
+def _pick(d, *keys):
+    return {k: d.get(k) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _sig(x, n=4):
+    """Numbers of the summary rounded to n significant digits (the full values are in the objects before it)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    return x
+
+
+def make_summary(out):
+    """The few numbers a reader of the LAST 2000 characters of the line needs (the driver keeps only the tail): headline value and
+    roofline fractions, bench-size parity, the lockstep kernel, and value / frac / parity / CPU baseline of every other config."""
+    roof, par, lock = out.get("roofline") or {}, out.get("parity") or {}, out.get("lockstep_kernel") or {}
+    sm = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_min_max": [out.get("ms_per_step_min"), out.get("ms_per_step_max")],
+          "kernel": roof.get("kernel"),
+          "roofline": _pick(roof, "frac", "frac_hi", "salu_issue_frac", "stale"),
+          "parity": _pick(par, "envs_checked", "mismatches"),
+          "cpu_baseline": _pick(out.get("cpu_baseline") or {}, "value", "cores"),
+          "lockstep_kernel": _pick(lock, "envs", "frac", "traffic_frac", "rocprof_avg_launch_us", "steady_state_us", "error")}
+    for name, e in (out.get("other_configs") or {}).items():
+        if not isinstance(e, dict):
+            continue
+        ent = _pick(e, "value", "error")
+        r = e.get("roofline") or {}
+        if r.get("frac") is not None:
+            ent["frac"] = r["frac"]
+        if isinstance(e.get("parity"), dict):
+            ent["parity_mismatches"] = e["parity"].get("mismatches")
+            ent["parity_envs"] = e["parity"].get("envs_checked")
+        if isinstance(e.get("cpu_baseline"), dict):
+            ent["cpu"] = e["cpu_baseline"].get("value")
+        sm[name] = ent
+    return _sig(sm)
+
+
+LINE_TAIL = ("roofline", "parity", "cpu_baseline", "summary")
+
+
+def order_line(out):
+    """Key order of the JSON line: the contract scalars first, then the bulky objects (config, other_configs, lockstep_kernel), then
+    roofline / parity / cpu_baseline, and the compact summary LAST so that it is what a 2000-character tail shows."""
+    out["summary"] = make_summary(out)
+    head = [k for k in out if k not in LINE_TAIL and not isinstance(out[k], dict)]
+    bulky = [k for k in out if k not in LINE_TAIL and isinstance(out[k], dict)]
+    return {k: out[k] for k in head + bulky + [k for k in LINE_TAIL if k in out]}
+
+
+def aux_failures(out):
+    """Auxiliary entries of the line that failed or disagree with the oracle (the headline parity exits 3 by itself)."""
+    bad = []
+    for name, e in (out.get("other_configs") or {}).items():
+        if isinstance(e, dict) and e.get("error"):
+            bad.append(f"other_configs.{name}: {e['error']}")
+        elif isinstance(e, dict) and isinstance(e.get("parity"), dict) and e["parity"].get("mismatches"):
+            bad.append(f"other_configs.{name}: {e['parity']['mismatches']} of {e['parity'].get('envs_checked')} envs differ from the oracle")
+    for name in ("lockstep_kernel", "cpu_baseline"):
+        if isinstance(out.get(name), dict) and out[name].get("error"):
+            bad.append(f"{name}: {out[name]['error']}")
+    return bad
+
+
+_INST = {}      # (A, T) -> (first, B, arrays): the largest block of instances generated so far for the shape
+
+
+def instances_block(A, T, first, B):
+    """generate_batch(B, A, T, base_seed=0, first=first), served from the block already generated for this shape when it covers
+    the range (the stream trials of a shard cut the same envs into 4 / 2 / 1 sub-batches: generated once, sliced)."""
+    hit = _INST.get((A, T))
+    if hit is not None and hit[0] <= first and first + B <= hit[0] + hit[1]:
+        o = first - hit[0]
+        return {k: v[o:o + B] for k, v in hit[2].items()}
+    inst = generate_batch(B, A, T, base_seed=0, first=first)
+    if hit is None or B >= hit[1]:
+        _INST[(A, T)] = (first, B, inst)
+    return inst
 
 
 class SubBatch:
@@ -395,7 +478,7 @@ class SubBatch:
     def __init__(self, cfg, first, B, dev, stream, visibility, reactive=True):
         A, T = cfg["agents"], cfg["tasks"]
         self.first, self.B, self.stream, self.replay, self.reactive = first, B, stream, cfg["kernel"].startswith("k_replay"), reactive
-        self.inst = generate_batch(B, A, T, base_seed=0, first=first)
+        self.inst = instances_block(A, T, first, B)
         self.seeds = env_seeds(0, first, B)
         self.env = BatchedTaskEnv(B, A, T, device=str(dev))
         self.env.load_instances(**self.inst)
@@ -435,8 +518,9 @@ def main():
     ap.add_argument("--visibility", default=None,
                     help="config 5: initial,batch,period,cap of the dynamic-arrival schedule (default: the reference's 20,20,10,100); "
                          "'static' = no dynamic arrivals at all (execute_by_route with reactive_planning False, every task routed)")
-    ap.add_argument("--dist-timeout", type=float, default=120.0,
-                    help="N > 1: seconds a rank waits in process-group bring-up / a collective before it fails with a reason")
+    ap.add_argument("--dist-timeout", type=float, default=None,
+                    help="N > 1: seconds a rank waits in process-group bring-up / a collective before it fails with a reason "
+                         "(default: $DCM_DIST_TIMEOUT, else 120)")
     ap.add_argument("--launch-timeout", type=float, default=None,
                     help="N > 1, self-launched: wall-clock limit of the whole job (dcmrta_amd/launch.py; default 1500 s, 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline AND the bench-size parity check)")
@@ -581,6 +665,8 @@ def main():
     local_steps = int(sum(int(torch.stack(sb.counts).sum().item()) for sb in subs))
     total_steps = ctx.sum_over_ranks(local_steps)
     launch_ms = [a.elapsed_time(b) for sb in subs for a, b in sb.ev]
+    # spread of the K timed passes: pass k = first launch start .. last launch end over the sub-batches (HIP events on their streams)
+    pass_ms = [max(sb.ev[k][0].elapsed_time(sb2.ev[k][1]) for sb in subs for sb2 in subs) for k in range(K)]
     warm_steps = int(sum(int(torch.stack(sb.warm).sum().item()) for sb in subs if sb.warm))
 
     for sb in subs:
@@ -689,6 +775,7 @@ def main():
                                + (f", one async all-gather of the {EP} episode return(s) of every env per pass" if ctx.active else ""),
                    "dist_backend": ctx.backend or None, "world": ctx.world, "process_group_ranks": ctx.group_size(), "rank_devices": device_names,
                    "self_launched": os.environ.get("DCM_SELF_LAUNCHED") is not None},
+        "ms_per_step_min": min(pass_ms), "ms_per_step_max": max(pass_ms),
         "roofline": roof,
         "parity": parity,
     }
@@ -714,8 +801,15 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(inst, np.concatenate([x.seeds for x in subs]), A)
         except Exception as ex:
             out["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    out = order_line(out)
     print(json.dumps(out), flush=True)
     ctx.shutdown()
+    bad_aux = aux_failures(out)
+    if bad_aux:
+        # (the headline parity has already exited 3 above; an auxiliary entry that failed or disagreed with the oracle must not
+        #  pass silently either)
+        print("bench.py: AUXILIARY FAILURE: " + "; ".join(bad_aux), file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -57,7 +57,19 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 #define PH_FLUSH(lane) do { if ((lane) == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); } while (0)
 #define PH_ARGS , unsigned long long& ph_t0, unsigned long long (&ph_acc)[12]
 #define PH_PASS , ph_t0, ph_acc
+// the register-resident persistent kernel (rollout_fast.hpp): its own marks, kept in the Fast<> object (tools/phase_fast.py)
+__device__ unsigned long long g_fast_cycles[16];
+#define FPH_MEMBERS mutable unsigned long long fph_t = 0, fph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FPH_START(f) ((f).fph_t = __builtin_readcyclecounter())
+#define FPH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); this->fph_acc[i] += t_ - this->fph_t; this->fph_t = t_; } while (0)
+#define FPHK(f, i) do { const unsigned long long t_ = __builtin_readcyclecounter(); (f).fph_acc[i] += t_ - (f).fph_t; (f).fph_t = t_; } while (0)
+#define FPH_FLUSH(f, lane) do { if ((lane) == 0) for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_fast_cycles[i_], (f).fph_acc[i_]); } while (0)
 #else
+#define FPH_MEMBERS
+#define FPH_START(f)
+#define FPH(i)
+#define FPHK(f, i)
+#define FPH_FLUSH(f, lane)
 #define PHK_DECL
 #define PHK_MARK(i)
 #define PHK_TOTAL(i)
@@ -67,6 +79,15 @@ __device__ unsigned long long g_step_rows[DCM_STEP_PROF_ENVS * 32];
 #define PH_FLUSH(lane)
 #define PH_ARGS
 #define PH_PASS
+#endif
+
+// Optional dynamic path counts of the register-resident rollout kernel (tools/path_counts.py builds a separate library with
+// -DDCM_COUNT_PATHS; behind profiles/r06_budget.md).  The product build compiles CNT() to nothing.
+#ifdef DCM_COUNT_PATHS
+__device__ unsigned long long g_path_counts[32];
+#define CNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_path_counts[i], 1ull); } while (0)
+#else
+#define CNT(i)
 #endif
 
 // ================================================================================== the simulator
@@ -1753,6 +1774,7 @@ struct DeviceGuard {
 
 }  // namespace
 
+#ifndef DCM_DEVICE_ONLY_TU   // (tools/loop_insts.py compiles single kernel instantiations of this file without the host API)
 extern "C" {
 
 const char* dcm_last_error(void) { return dcm::g_err; }
@@ -1761,6 +1783,16 @@ int dcm_abi_version(void) { return DCM_ABI_VERSION; }
 #define DCM_BUILD_ID "unknown"
 #endif
 const char* dcm_build_id(void) { return DCM_BUILD_ID; }
+#ifdef DCM_COUNT_PATHS
+// developer build only (tools/path_counts.py): read and clear the dynamic path counts of the register-resident rollout kernel
+int dcm_debug_path_counts(unsigned long long* out32) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_path_counts), 32 * sizeof(unsigned long long)));
+    static const unsigned long long zero[32] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_path_counts), zero, sizeof(zero)));
+    return 0;
+}
+#endif
 
 int dcm_create(const dcm_params* params, dcm_env** out) {
     if (!params || !out) return fail(DCM_ERR_INVALID, "dcm_create: null argument");
@@ -2163,6 +2195,12 @@ int dcm_distance(const double* ax, const double* ay, const double* bx, const dou
 }
 
 #ifdef DCM_PROFILE_PHASES
+int dcm_prof_read_fast(unsigned long long* out16, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fast_cycles), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_cycles), z, sizeof(z))); }
+    return 0;
+}
 int dcm_prof_read(unsigned long long* out16, int reset) {
     HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 16));
     if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z))); }
@@ -2184,3 +2222,4 @@ int dcm_record_bytes(dcm_env* env, size_t* bytes_out) {
 }
 
 }  // extern "C"
+#endif  // DCM_DEVICE_ONLY_TU

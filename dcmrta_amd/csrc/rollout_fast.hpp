@@ -46,6 +46,7 @@ struct Fast {
                                                        // (became feasible) the fast path has changed: the write-back sends their 64-byte
                                                        // pieces of those sections instead of the sections
     mutable bool calm = false;                         // the last task_update call left every task at a fixed point for its `now`
+    FPH_MEMBERS;
     uint64_t am, tm;                                   // lanes that own an agent / a task (wave-uniform masks)
     // per-lane constants
     bool inA, inT, isD;
@@ -146,6 +147,7 @@ struct Fast {
         int nn = n;
         const uint64_t dmask = __ballot(any_drop);
         if (dmask) {
+            CNT(6);
             // Members leave (:262-265 spread branch, :268-271 waiting branch with its remove-while-iterating skip, Q1).  The
             // task's lane compacts its own slots; the agents' lanes then take their abandonment from the task's `gone` mask --
             // no scatter through LDS: an agent's counters live in its own lane.
@@ -199,6 +201,7 @@ struct Fast {
             if constexpr (TRK) dirty |= SimT::DIRTY_ALL & ~SimT::DIRTY_TIMES;   // slots compacted: every arrival row, ids, counts
             uint64_t todo = dmask;
             do {
+                CNT(7);
                 const int t = __ffsll((unsigned long long)todo) - 1;
                 todo &= todo - 1ull;
                 const uint64_t g = rl(gone, t);
@@ -223,6 +226,7 @@ struct Fast {
         calm = dmask == 0ull && __ballot(becomes && inT && now >= ntf) == 0ull;
         WSYNC();
         if (all_feasible) {                                                      // depot :277-280
+            CNT(16);
             if ((r.ai & A_INDEPOT) && now >= r.arr) r.ai |= A_RETURNED;
         }
     }
@@ -282,18 +286,29 @@ struct Fast {
         if (glen == 0) return -1;
         return nth(gm, below((uint32_t)(k1 >> 32), glen));
     }
-    __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp) const {
+    // UPD = false: without the closing task_update / agent_update (the caller runs them; `quiet_out` = the task_update can be skipped)
+    template <bool UPD = true>
+    __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp,
+                                          bool* quiet_out = nullptr) const {
         uint64_t gm;
-        const int leader = pick_leader(r, h, k1, gm);
-        if (leader < 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return 0; }    // unreachable: groups are never empty
+        // (no early return: an exit from the middle of a decision would keep the whole register set of the agent / task state alive
+        //  in a second copy -- 15 v_mov per decision at the loop latch.  An empty group is unreachable; if it ever happened the env
+        //  is flagged and stops at the loop's ordinary exit test, its state no longer meaningful.)
+        int leader = pick_leader(r, h, k1, gm);
+        if (leader < 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; leader = 0; gm = 1ull; }
+        FPH(0);
         const uint64_t bm = observe(r, h.now, leader, agrow, tkrow, mkp);
+        FPH(1);
         // uniform-random valid action (protocol slot 1)
         const int nv = __popcll(bm);
         const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
-        return apply(r, h, P, lane, k1, gm, leader, action);
+        FPH(2);
+        return apply<UPD>(r, h, P, lane, k1, gm, leader, action, quiet_out);
     }
     // TaskEnv.step :326-342 with the leader's (valid: unmasked task or depot) action, then task_update / agent_update
-    __device__ __forceinline__ int apply(R& r, const HdrRegs& h, const KP& P, int lane, uint64_t k1, uint64_t gm, int leader, int action) const {
+    template <bool UPD = true>
+    __device__ __forceinline__ int apply(R& r, const HdrRegs& h, const KP& P, int lane, uint64_t k1, uint64_t gm, int leader, int action,
+                                         bool* quiet_out = nullptr) const {
         const double now = h.now;
         uint64_t rest = gm & ~(1ull << leader);                                  // :328
         int rlen = __popcll(gm) - 1;
@@ -302,12 +317,14 @@ struct Fast {
         int mypos = 0;                                                           // this lane's position in the step's member list
         const int tl = action ? action - 1 : DL;                                 // lane that owns the target
         if (action == 0) {                                                       // vacancy = len(group) :327 (Q9)
+            CNT(2);
             mm |= rest; nm += rlen; rlen = 0;
         } else if (rlen != 0) {
             const int vacancy = (int)(int8_t)(((uint32_t)__builtin_amdgcn_readlane((int)r.ti, tl) >> 8) & 0xFF);   // :327 (may be stale)
             const int nf = (vacancy > 1) ? ((vacancy - 1 < rlen) ? vacancy - 1 : rlen) : 0;   // :330-331
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                       // :331 choice without replacement
+                CNT(1);
                 if ((j & 1) == 0) kk = mix64(kk + GAMMA);
                 const uint32_t rr = (j & 1) ? (uint32_t)kk : (uint32_t)(kk >> 32);
                 const int f = nth(rest, below(rr, rlen));
@@ -319,12 +336,14 @@ struct Fast {
                 nm++;
             }
         }
+        FPH(3);
         const double tx_ = rl(r.tx, tl), ty_ = rl(r.ty, tl);
         // agent_step :300-324 on ALL lanes (fp64 VALU work with fewer than 16 active lanes is 4x slower on gfx950; the asm
         // statement keeps the compiler from sinking the chain into the members-only block below)
         double d = dist2(r.ax, r.ay, tx_, ty_);
         double arrv = now + over_velocity(d);                                    // :315,:318
         asm volatile("" : "+v"(d), "+v"(arrv));
+        FPH(4);
         const bool mem = (mm >> lane) & 1ull;
         uint64_t ids = 0ull; uint32_t kinfo = 0; int n = 0;
         int slot = 0;
@@ -339,6 +358,7 @@ struct Fast {
                 dt_join |= 1ull << tl;
             }
             if (rl(r.lm, tl) & mm) {
+                CNT(3);
                 // rare (Q4): walk the members in order as the reference does; every member's lane learns its own slot
                 for (int j = 0; j < nm; j++) {
                     const int m = (int)((mlist >> (8 * j)) & 0xFF);
@@ -377,8 +397,13 @@ struct Fast {
             if (quiet) S.tinfo()[lt] = r.ti;                                     // (written through like task_update does)
         }
         WSYNC();
-        if (!quiet) task_update(r, now, P.mwt, lane);                            // worker.py:74
-        agent_update(r, now, P.mwt);                                             // worker.py:76
+        FPH(5);
+        if constexpr (UPD) {
+            if (!quiet) { CNT(5); task_update(r, now, P.mwt, lane); } else CNT(4);     // worker.py:74
+            FPH(6);
+            agent_update(r, now, P.mwt);                                             // worker.py:76
+            FPH(7);
+        } else *quiet_out = quiet;
         return rlen;
     }
 
@@ -386,17 +411,25 @@ struct Fast {
     // Boxes D + A of the loop when somebody can decide and MAX_TIME has not passed: next_decision (env/task_env.py:283-289),
     // get_unique_group (:291-298), task_update, agent_update (worker.py:49-51).  Returns false -- with nothing changed -- when the
     // event needs the general code (nobody can decide: check_finished :366-373; or the loop test of worker.py:45 ends the episode).
+    template <bool UPD = true>
     __device__ __forceinline__ bool next_event(R& r, HdrRegs& h, const KP& P, int lane) const {
+        FPH(8);
         if (h.now >= P.max_time) return false;
         const double ndv = inA ? r.nd : __builtin_nan("");
+#ifdef DCM_UMIN
+        const double tmin = wave_nanmin_pos<CA>(ndv);                            // :287 (times are never negative here)
+#else
         const double tmin = wave_nanmin_n<CA>(ndv);                              // :287
+#endif
         if (!(tmin == tmin)) return false;
+        CNT(10);
         h.now = tmin;                                                            // worker.py:49
         const bool dec = (ndv == tmin);                                          // :288 exact ==
         const uint64_t dm = __ballot(dec);
         const int first = __ffsll((unsigned long long)dm) - 1;
         bool same = true;
         if (dm & (dm - 1ull)) {                                                  // more than one decider: all on one point?
+            CNT(12);
             const double x0 = rl(r.ax, first), y0 = rl(r.ay, first);
             same = __ballot(dec && !(r.ax == x0 && r.ay == y0)) == 0ull;
         }
@@ -404,11 +437,13 @@ struct Fast {
             r.ai = (r.ai & ~A_GRP) | (dec ? (1u << 8) : 0u);
             h.n_groups = 1;
         } else {
+            CNT(13);
             // groups in ascending (x, then y) order == rows of np.unique(axis=0) :293
             bool todo = dec;
             uint32_t gid = 0;
             int g = 0;
             for (;;) {
+                CNT(14);
                 const double mxv = wave_nanmin_n<CA>(todo ? r.ax : __builtin_nan(""));
                 if (!(mxv == mxv)) break;
                 const double myv = wave_nanmin_n<CA>((todo && r.ax == mxv) ? r.ay : __builtin_nan(""));
@@ -418,8 +453,13 @@ struct Fast {
             r.ai = (r.ai & ~A_GRP) | (gid << 8);
             h.n_groups = g;
         }
-        task_update(r, tmin, P.mwt, lane);                                       // worker.py:50
-        agent_update(r, tmin, P.mwt);                                            // worker.py:51
+        FPH(9);
+        if constexpr (UPD) {
+            task_update(r, tmin, P.mwt, lane);                                       // worker.py:50
+            FPH(10);
+            agent_update(r, tmin, P.mwt);                                            // worker.py:51
+            FPH(11);
+        }
         h.empty_passes = 0;
         h.cur_group = 1;
         return true;
@@ -468,9 +508,14 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     const int left0 = uni((int)((bud < 0 || bud >= NO_BUDGET) ? NO_BUDGET : bud));
     int left = left0;
     uint64_t gd = h.seed + GAMMA * (h.d + 1);
+    // the choice-protocol keys of the next 64 decisions, one per lane (25 VALU instructions per 64 decisions instead of a dependent
+    // chain of 20 scalar ones at the head of every decision); ki = the lane that holds the current decision's key
+    uint64_t kv = mix64(gd + GAMMA * (uint64_t)lane);
+    int ki = 0;
     const uint64_t d0 = h.d;
     typename F::R r;
     f.load_consts(r);
+    FPH_START(f);
     constexpr uint32_t ERR = DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE;
     PH_DECL;
     int ep = 0;
@@ -486,6 +531,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
             }
         }
         if (need_adv) {
+            CNT(15);
             S.advance(h, P, lane, row PH_PASS);
             need_adv = false;
             // wave-uniform by construction; tell the compiler so (scalar branches in the fast loop)
@@ -495,25 +541,33 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
         if (!(h.flags & DCM_FLAG_DONE) && left != 0) {
             WSYNC();
             f.reload(r);
+            FPHK(f, 13);
             for (;;) {
-                const uint64_t k1 = mix64(gd);
+                FPHK(f, 12);
+                CNT(0);
+                const uint64_t k1 = F::rl(kv, ki);
                 const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
+                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); ki = 0; }
                 left--;
                 if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
-                    if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group
+                    CNT(8);
+                    if (h.cur_group < h.n_groups) { CNT(9); h.cur_group++; }                  // worker.py:52 next group
                     else if (!f.next_event(r, h, P, lane)) { need_adv = true; break; }   // worker.py:85 -> :45
                 }
                 if (left == 0) break;
             }
             f.flush(r);
+            FPHK(f, 12);
             if (need_adv) continue;
         }
         if (left == 0) break;
         ep++;
     }
     PH_FLUSH(lane);
+    FPHK(f, 13);
+    FPH_FLUSH(f, lane);
     const int64_t steps = (int64_t)(left0 - left);
     if (lane == 0 && steps_out) steps_out[e] = steps;
     h.d = d0 + (uint64_t)steps;

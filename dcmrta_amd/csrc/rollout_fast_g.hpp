@@ -349,7 +349,9 @@ struct FastG {
             gm[ac] = __ballot((int)((r.ai[ac] >> 8) & 0xFFu) == h.cur_group) & amask(ac);
             glen += __popcll(gm[ac]);
         }
-        if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; return 0; }    // unreachable: groups are never empty
+        // (unreachable: groups are never empty.  No early return -- see Fast::decide: an exit from the middle of a decision keeps a
+        //  second copy of the whole lane-owned state alive)
+        if (glen == 0) { h.flags |= DCM_FLAG_BAD_LEADER | DCM_FLAG_DONE; glen = 1; gm[0] = 1ull; }
         const int leader = nth_agent(gm, below((uint32_t)(k1 >> 32), glen));
         const double now = h.now;
         const BM bm = observe(r, now, leader, lane, ag, tk, mk);

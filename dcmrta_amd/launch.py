@@ -104,8 +104,15 @@ def _stop_tree(proc, grace=10.0):
     ends them too) -- SIGTERM, a grace period, then SIGKILL for what is left of those pids."""
     pids = [proc.pid] + _descendants(proc.pid)
     for sig in (signal.SIGTERM, signal.SIGKILL):
-        for pid in pids:
-            if pid == proc.pid or _alive(pid):
+        # the launcher child through its Popen handle (a no-op once it has been reaped: its pid may belong to someone else by
+        # then); the ranks below it by pid, only while /proc still shows them alive
+        if proc.poll() is None:
+            try:
+                proc.send_signal(sig)
+            except (ProcessLookupError, PermissionError):
+                pass
+        for pid in pids[1:]:
+            if _alive(pid):
                 try:
                     os.kill(pid, sig)
                 except (ProcessLookupError, PermissionError):
@@ -121,8 +128,9 @@ def _stop_tree(proc, grace=10.0):
             return
 
 
-def launch_ranks(script, argv, n, timeout=DEFAULT_LAUNCH_TIMEOUT_S):
-    """Start the N ranks as a child process tree and wait at most `timeout` seconds (None = forever).  Returns the exit code
+def launch_ranks(script, argv, n, timeout=None):
+    """Start the N ranks as a child process tree and wait at most `timeout` seconds (None, the library default = forever; the
+    scripts' `--launch-timeout` applies DEFAULT_LAUNCH_TIMEOUT_S through maybe_self_launch).  Returns the exit code
     (non-zero if any rank failed: torch.distributed.run tears the others down and reports it); on expiry the child tree is
     ended and the exit code is 124 with a one-line reason on stderr.  The ranks are always FRESH children of a parent that
     never touched the GPU -- nothing is re-exec'ed."""

@@ -185,6 +185,17 @@ def test_default_line_times_the_other_baseline_configs(gpu_device):
     lim = j["config"]["limits"]
     assert lim["members_per_task"] == 5 and lim["members_per_task_wide_handle"] == 16 and lim["A"] == 128 and lim["T"] == 1023
     assert j["config"]["rank_devices"] and j["config"]["rank_devices"][0].startswith("cuda:")
+    # the compact summary is the LAST key and fits the 2000-character tail the driver keeps; it repeats the numbers a reader needs
+    assert out.returncode == 0
+    assert list(j)[-1] == "summary" and list(j)[-4:] == ["roofline", "parity", "cpu_baseline", "summary"]
+    sm = j["summary"]
+    assert len(json.dumps(sm)) < 1500 and lines[0].rstrip().endswith(json.dumps(sm) + "}")
+    assert sm["parity"] == {"envs_checked": 4096, "mismatches": 0} and sm["value"] > 1e6 and "frac" in sm["roofline"]
+    assert sm["lockstep_kernel"]["frac"] > 0 and sm["lockstep_kernel"].get("steady_state_us", 1) > 0
+    for name in ("config4_shard", "config5_shard", "midsize_70A130T"):
+        assert sm[name]["value"] > 1e8 and sm[name]["parity_mismatches"] == 0 and sm[name]["cpu"] > 0, name
+    assert sm["config3"]["value"] > 1e4
+    assert 0 < j["ms_per_step_min"] <= j["ms_per_step_max"]
 
 
 def test_unprofiled_shape_borrows_the_counters_of_its_kernel(gpu_device):

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "tools", "libdcmrta_dbg.so")
 src = os.path.join(ROOT, "dcmrta_amd", "csrc")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-mllvm", "-phi-elim-split-all-critical-edges=1",
                        "-shared", "-DDCM_INC_DEBUG", os.path.join(src, "dcmrta_env.hip"), os.path.join(src, "dcmrta_replay.hip"), "-o", so])
 from dcmrta_amd import _lib  # noqa: E402
 _lib.LIB_PATH = so

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "tools", "libdcmrta_prof.so")
 src = os.path.join(ROOT, "dcmrta_amd", "csrc")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-phi-elim-split-all-critical-edges=1",
                        "-fPIC", "-shared", "-DDCM_PROFILE_PHASES", os.path.join(src, "dcmrta_env.hip"),
                        os.path.join(src, "dcmrta_replay.hip"), "-o", so])
 import torch  # noqa: E402

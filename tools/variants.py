@@ -17,7 +17,7 @@ variants = []
 for spec in sys.argv[1:]:
     name, _, flags = spec.partition(":")
     so = os.path.join(out, f"lib_{name}.so")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-mllvm", "-phi-elim-split-all-critical-edges=1",
            "-shared"] + flags.split() + [os.path.join(src, "dcmrta_env.hip"), os.path.join(src, "dcmrta_replay.hip"), "-o", so]
     subprocess.check_call(cmd)
     variants.append((name, so))
