@@ -665,8 +665,9 @@ def main():
     local_steps = int(sum(int(torch.stack(sb.counts).sum().item()) for sb in subs))
     total_steps = ctx.sum_over_ranks(local_steps)
     launch_ms = [a.elapsed_time(b) for sb in subs for a, b in sb.ev]
-    # spread of the K timed passes: pass k = first launch start .. last launch end over the sub-batches (HIP events on their streams)
-    pass_ms = [max(sb.ev[k][0].elapsed_time(sb2.ev[k][1]) for sb in subs for sb2 in subs) for k in range(K)]
+    # spread of the timed passes: the passes of different sub-batches overlap (that is what the streams are for), so a pass is timed
+    # by its completion -- end of pass k minus end of pass k-1 on the same stream, averaged over the sub-batches (HIP events)
+    pass_ms = [float(np.mean([sb.ev[k - 1][1].elapsed_time(sb.ev[k][1]) for sb in subs])) for k in range(1, K)] or [elapsed / K * 1e3]
     warm_steps = int(sum(int(torch.stack(sb.warm).sum().item()) for sb in subs if sb.warm))
 
     for sb in subs:

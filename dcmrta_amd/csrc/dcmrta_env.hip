@@ -26,12 +26,27 @@
 
 using namespace dcm;
 
+// Translation units (Makefile).  The library is built from this file twice: the main unit (-DDCM_SPLIT_G: every kernel but the
+// mid-size persistent one, which it reaches through dcm::launch_rollout_fast_g) with -mllvm -phi-elim-split-all-critical-edges=1,
+// and the unit of k_rollout_fast_g alone (-DDCM_TU_G) without that option -- it costs that kernel 4 % (8.19 -> 8.53 ms per 4096 x
+// 70A/130T launch) while it buys the one-chunk and the 50A/200T kernel 2.1 % / 1.3 %.  With neither macro (the developer tools'
+// one-command builds) everything is in one unit.
+#ifdef DCM_TU_G
+#define DCM_DEVICE_ONLY_TU 1
+#endif
 namespace dcm {
+#ifndef DCM_TU_G
 thread_local char g_err[512] = "";
 int fail(int code, const char* fmt, const char* a, const char* b) {
     snprintf(g_err, sizeof(g_err), fmt, a, b);
     return code;
 }
+#endif
+// k_rollout_fast_g<NAC, NTC, OBS> (rollout_fast_g.hpp): same arguments as the kernel behind the launch geometry
+void launch_rollout_fast_g(int nac, int ntc, bool obs, unsigned grid, unsigned lds_bytes, hipStream_t stream, int A, int T, int PA, int PT,
+                           KP kp, unsigned char* state, int episodes, float* agents_out, float* tasks_out, uint8_t* mask_out,
+                           int64_t* steps_out, double* summary, uint16_t* ablog, const int32_t* sizes, int64_t budget_all,
+                           const int64_t* budget_in, unsigned char* gscr, double* retlog, int retcap);
 }  // namespace dcm
 
 namespace {
@@ -1614,7 +1629,9 @@ __global__ __launch_bounds__(WAVE, 3) void k_rollout_random(int A, int T, int PA
 #include "rollout_fast.hpp"
 #include "step_fast.hpp"
 #include "rollout_fast_mc.hpp"
+#if defined(DCM_TU_G) || !defined(DCM_SPLIT_G)
 #include "rollout_fast_g.hpp"
+#endif
 
 __global__ __launch_bounds__(WAVE) void k_env_status(int PA, int PT, int PC, const unsigned char* state, int B, uint32_t* flags_out,
                                                     int64_t* dec_out, double* now_out, int32_t* episodes_out) {
@@ -1773,6 +1790,23 @@ struct DeviceGuard {
 };
 
 }  // namespace
+
+#if defined(DCM_TU_G) || !defined(DCM_SPLIT_G)
+void dcm::launch_rollout_fast_g(int nac, int ntc, bool obs, unsigned grid, unsigned lds_bytes, hipStream_t stream, int A, int T, int PA, int PT,
+                                KP kp, unsigned char* state, int episodes, float* agents_out, float* tasks_out, uint8_t* mask_out,
+                                int64_t* steps_out, double* summary, uint16_t* ablog, const int32_t* sizes, int64_t budget_all,
+                                const int64_t* budget_in, unsigned char* gscr, double* retlog, int retcap) {
+#define CALLG(NAC, NTC, OBS)                                                                                           \
+    hipLaunchKernelGGL((k_rollout_fast_g<NAC, NTC, OBS>), dim3(grid), dim3(WAVE), lds_bytes, stream, A, T, PA, PT, kp, state, episodes, \
+                       agents_out, tasks_out, mask_out, steps_out, summary, ablog, sizes, budget_all, budget_in, gscr, retlog, retcap)
+#define CALLT(NAC, OBS) do { if (ntc > 3) { CALLG(NAC, 4, OBS); } else if (ntc > 2) { CALLG(NAC, 3, OBS); } else { CALLG(NAC, 2, OBS); } } while (0)
+#define CALLA(OBS) do { if (nac > 1) { CALLT(2, OBS); } else { CALLT(1, OBS); } } while (0)
+    if (obs) { CALLA(true); } else { CALLA(false); }
+#undef CALLA
+#undef CALLT
+#undef CALLG
+}
+#endif
 
 #ifndef DCM_DEVICE_ONLY_TU   // (tools/loop_insts.py compiles single kernel instantiations of this file without the host API)
 extern "C" {
@@ -2054,16 +2088,10 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     // Every other batch of the mid-size class (A <= 128, T <= 256; uniform or ragged): rollout_fast_g.hpp, chunk counts from the batch dims
     if (quiet_ok && env->L.C == M && env->A <= 128 && env->T <= 256 && !(env->L.A == 20 && env->L.T == 50) && !(env->L.A == 64 && env->L.T == 64) &&
         (all_obs || no_obs)) {
-#define CALLG(NAC, NTC, OBS)                                                                                           \
-    hipLaunchKernelGGL((k_rollout_fast_g<NAC, NTC, OBS>), GRID(env), (Sim<128, 256, true>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, \
-                       DIMS(env), env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
-                       (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
-#define CALLT(NAC, OBS) do { if (env->T > 192) { CALLG(NAC, 4, OBS); } else if (env->T > 128) { CALLG(NAC, 3, OBS); } else { CALLG(NAC, 2, OBS); } } while (0)
-#define CALLA(OBS) do { if (env->A > 64) { CALLT(2, OBS); } else { CALLT(1, OBS); } } while (0)
-        if (all_obs) { CALLA(true); } else { CALLA(false); }
-#undef CALLA
-#undef CALLT
-#undef CALLG
+        dcm::launch_rollout_fast_g(env->A > 64 ? 2 : 1, env->T > 192 ? 4 : (env->T > 128 ? 3 : 2), all_obs, (unsigned)env->p.n_envs,
+                                   (unsigned)(Sim<128, 256, true>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), env->kp,
+                                   env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog,
+                                   (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap);
         LAUNCH_OK();
         return DCM_OK;
     }

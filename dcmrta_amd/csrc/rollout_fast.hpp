@@ -288,8 +288,9 @@ struct Fast {
     }
     // UPD = false: without the closing task_update / agent_update (the caller runs them; `quiet_out` = the task_update can be skipped)
     template <bool UPD = true>
+    // k2p: the decision's second key mix64(k1 + GAMMA) (the first two follower draws) if the caller has it, else nullptr
     __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp,
-                                          bool* quiet_out = nullptr) const {
+                                          bool* quiet_out = nullptr, const uint64_t* k2p = nullptr) const {
         uint64_t gm;
         // (no early return: an exit from the middle of a decision would keep the whole register set of the agent / task state alive
         //  in a second copy -- 15 v_mov per decision at the loop latch.  An empty group is unreachable; if it ever happened the env
@@ -303,12 +304,12 @@ struct Fast {
         const int nv = __popcll(bm);
         const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
         FPH(2);
-        return apply<UPD>(r, h, P, lane, k1, gm, leader, action, quiet_out);
+        return apply<UPD>(r, h, P, lane, k1, gm, leader, action, quiet_out, k2p);
     }
     // TaskEnv.step :326-342 with the leader's (valid: unmasked task or depot) action, then task_update / agent_update
     template <bool UPD = true>
     __device__ __forceinline__ int apply(R& r, const HdrRegs& h, const KP& P, int lane, uint64_t k1, uint64_t gm, int leader, int action,
-                                         bool* quiet_out = nullptr) const {
+                                         bool* quiet_out = nullptr, const uint64_t* k2p = nullptr) const {
         const double now = h.now;
         uint64_t rest = gm & ~(1ull << leader);                                  // :328
         int rlen = __popcll(gm) - 1;
@@ -325,7 +326,7 @@ struct Fast {
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                       // :331 choice without replacement
                 CNT(1);
-                if ((j & 1) == 0) kk = mix64(kk + GAMMA);
+                if ((j & 1) == 0) kk = (j == 0 && k2p) ? *k2p : mix64(kk + GAMMA);
                 const uint32_t rr = (j & 1) ? (uint32_t)kk : (uint32_t)(kk >> 32);
                 const int f = nth(rest, below(rr, rlen));
                 rest &= ~(1ull << f); rlen--;                                    // :332-333
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     // the choice-protocol keys of the next 64 decisions, one per lane (25 VALU instructions per 64 decisions instead of a dependent
     // chain of 20 scalar ones at the head of every decision); ki = the lane that holds the current decision's key
     uint64_t kv = mix64(gd + GAMMA * (uint64_t)lane);
+    uint64_t kv2 = mix64(kv + GAMMA);                  // ... and their second keys (follower draws 0 and 1)
     int ki = 0;
     const uint64_t d0 = h.d;
     typename F::R r;
@@ -545,11 +547,11 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
             for (;;) {
                 FPHK(f, 12);
                 CNT(0);
-                const uint64_t k1 = F::rl(kv, ki);
-                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp);
+                const uint64_t k1 = F::rl(kv, ki), k2 = F::rl(kv2, ki);
+                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, nullptr, &k2);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
-                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); ki = 0; }
+                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; }
                 left--;
                 if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
                     CNT(8);
