@@ -79,12 +79,25 @@ __device__ unsigned long long g_fast_cycles[16];
 #define FPH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); this->fph_acc[i] += t_ - this->fph_t; this->fph_t = t_; } while (0)
 #define FPHK(f, i) do { const unsigned long long t_ = __builtin_readcyclecounter(); (f).fph_acc[i] += t_ - (f).fph_t; (f).fph_t = t_; } while (0)
 #define FPH_FLUSH(f, lane) do { if ((lane) == 0) for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_fast_cycles[i_], (f).fph_acc[i_]); } while (0)
+#elif defined(DCM_PHASE_MARKS)
+// tools/loop_insts.py --phases: the same marks as assembler comments, to attribute the decision loop's instructions to phases
+#define FPH_MEMBERS
+#define FPH_START(f)
+#define FPH(i) asm volatile("; FPHMARK " #i)
+#define FPHK(f, i) asm volatile("; FPHMARK " #i)
+#define FPH_FLUSH(f, lane)
+#define FPM(i) asm volatile("; FPHMARK " #i)     // sub-phase brackets (20/21 member removal, 22/23 one follower draw): marks mode only
 #else
 #define FPH_MEMBERS
 #define FPH_START(f)
 #define FPH(i)
 #define FPHK(f, i)
 #define FPH_FLUSH(f, lane)
+#endif
+#ifndef FPM
+#define FPM(i)
+#endif
+#ifndef DCM_PROFILE_PHASES
 #define PHK_DECL
 #define PHK_MARK(i)
 #define PHK_TOTAL(i)

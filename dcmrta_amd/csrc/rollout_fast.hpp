@@ -125,7 +125,8 @@ struct Fast {
     // ------------------------------------------------------------------------------ task_update, env/task_env.py:245-281
     // One lane per task, inputs from the lane's registers + the member arrival slots in LDS.  Returns with tinfo / time_start /
     // time_finish written through for agent_update's gather.
-    __device__ __forceinline__ void task_update(R& r, double now, double mwt, int lane) const {
+    // (site: which call this is -- path counters of the developer builds only)
+    __device__ __forceinline__ void task_update(R& r, double now, double mwt, int lane, int site = 0) const {
         uint32_t info = r.ti;
         const bool feas0 = info & T_FEAS;
         const int req = info & 0xFF, n = (info >> 16) & 0xFF;                    // :250
@@ -134,6 +135,32 @@ struct Fast {
         for (int j = 0; j < M; j++) av[j] = S.marr()[j * CT + lt];               // :251 (unused slots hold NaN)
         const double tfin = r.tf, dur = r.dur;
         const int status = req - n;                                              // :252
+#ifdef DCM_TU_SKIP
+        // The latest arrival only matters for a task whose coalition is complete (status <= 0 :254): the spread test, time_start and
+        // the spread rule's threshold (:255-265).  Such a task exists at the one call after the completing join (or while a stale
+        // status lingers, Q3); every other call -- wave-uniform test -- skips the four v_max_f64 and the tests that need them.
+        double mn = av[0];
+#pragma unroll
+        for (int j = 1; j < M; j++) mn = nanmin2(mn, av[j]);
+        const bool le0 = status <= 0;                                            // :254
+        double mx = 0.0, thr = 0.0;
+        bool ok = false;
+        if (__ballot(inT && !feas0 && le0)) {
+            mx = av[0];
+#pragma unroll
+            for (int j = 1; j < M; j++) mx = nanmax2(mx, av[j]);
+            ok = le0 && (mx - mn <= mwt);                                        // :255
+            thr = mx - mwt;                                                      // :262
+        }
+        // does any member leave?  (see Sim::task_update: decided on the earliest arrival alone)
+        const bool any_drop = inT && !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
+        const bool becomes = !feas0 && ok;                                       // :256-258
+        // time_start / time_finish change -- and are written through for agent_update's gather -- only when a task becomes feasible
+        // (:256-257): wave-uniform test
+        const uint64_t bec = __ballot(becomes && inT);
+        double nts = r.ts, ntf = tfin;
+        if (bec) { nts = becomes ? mx : nts; ntf = becomes ? mx + dur : ntf; }
+#else
         double mx = av[0], mn = av[0];
 #pragma unroll
         for (int j = 1; j < M; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
@@ -144,10 +171,12 @@ struct Fast {
         const bool any_drop = inT && !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
         const bool becomes = !feas0 && ok;                                       // :256-258
         const double nts = becomes ? mx : r.ts, ntf = becomes ? mx + dur : tfin;
+#endif
         int nn = n;
         const uint64_t dmask = __ballot(any_drop);
         if (dmask) {
-            CNT(6);
+            CNT(6 + site);
+            FPM(20);
             // Members leave (:262-265 spread branch, :268-271 waiting branch with its remove-while-iterating skip, Q1).  The
             // task's lane compacts its own slots; the agents' lanes then take their abandonment from the task's `gone` mask --
             // no scatter through LDS: an agent's counters live in its own lane.
@@ -175,7 +204,9 @@ struct Fast {
                 // Compact the survivors in order, without a branch: vacate all slots, then every surviving member moves down to
                 // its rank among the survivors (a target never lies above its source, so earlier writes are never clobbered);
                 // the leavers' writes go to a per-lane dummy slot.  At least one listed member leaves, so at most four survive:
-                // their ids fit the low word.
+                // their ids fit the low word.  (Writing each slot straight to its final place -- survivors to their rank, leavers
+                // as NaN behind them: five writes instead of ten, no dummy slot -- was tried in round 6: +20 VALU for the target
+                // and value selects, not faster.)
                 const uint32_t idl = (uint32_t)r.ids, idh = (uint32_t)(r.ids >> 32);
                 uint32_t nids = 0;
                 using gone_t = typename std::conditional<(CA <= 32), uint32_t, uint64_t>::type;   // agent ids below 32: one word
@@ -213,10 +244,26 @@ struct Fast {
                     if (r.cur == t) r.ai &= ~A_MEMBER;                           // no longer `agent in current_task['members']` :230
                 }
             } while (todo);
+            FPM(21);
         }
         const uint32_t info_i = ((info | (ok ? T_FEAS : 0u)) & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
         const uint32_t info_f = info | ((now >= tfin) ? T_FIN : 0u);             // :273-274
         info = feas0 ? info_f : info_i;
+#ifdef DCM_TU_SKIP
+        r.ti = info;
+        if (inT) S.tinfo()[lt] = info;
+        bool over_already = false;
+        if (bec) {
+            r.ts = nts; r.tf = ntf;
+            if (inT) { S.ts()[lt] = nts; S.tf()[lt] = ntf; }
+            if constexpr (TRK) { dirty |= SimT::DIRTY_TIMES; dt_times |= bec; }
+            over_already = __ballot(becomes && inT && now >= ntf) != 0ull;
+        }
+        const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
+        // (see Sim::task_update: a call can only change a task again at the same `now` if this one removed members or made a task
+        //  feasible that is already over)
+        calm = dmask == 0ull && !over_already;
+#else
         r.ti = info; r.ts = nts; r.tf = ntf;
         if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
         if constexpr (TRK) { const uint64_t bb = __ballot(becomes && inT); if (bb) { dirty |= SimT::DIRTY_TIMES; dt_times |= bb; } }
@@ -224,6 +271,7 @@ struct Fast {
         // (see Sim::task_update: a call can only change a task again at the same `now` if this one removed members or made a task
         //  feasible that is already over)
         calm = dmask == 0ull && __ballot(becomes && inT && now >= ntf) == 0ull;
+#endif
         WSYNC();
         if (all_feasible) {                                                      // depot :277-280
             CNT(16);
@@ -326,6 +374,7 @@ struct Fast {
             uint64_t kk = k1;
             for (int j = 0; j < nf; j++) {                                       // :331 choice without replacement
                 CNT(1);
+                FPM(22);
                 if ((j & 1) == 0) kk = (j == 0 && k2p) ? *k2p : mix64(kk + GAMMA);
                 const uint32_t rr = (j & 1) ? (uint32_t)kk : (uint32_t)(kk >> 32);
                 const int f = nth(rest, below(rr, rlen));
@@ -335,6 +384,7 @@ struct Fast {
                 // lane f takes its list position
                 mypos = lane == f ? nm : mypos;
                 nm++;
+                FPM(23);
             }
         }
         FPH(3);
@@ -456,7 +506,7 @@ struct Fast {
         }
         FPH(9);
         if constexpr (UPD) {
-            task_update(r, tmin, P.mwt, lane);                                       // worker.py:50
+            task_update(r, tmin, P.mwt, lane, 11);                                   // worker.py:50
             FPH(10);
             agent_update(r, tmin, P.mwt);                                            // worker.py:51
             FPH(11);

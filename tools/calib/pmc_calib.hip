@@ -18,11 +18,13 @@
 #include <vector>
 
 enum Op { FMA_F64, ADD_F64, MIN_F64, CVT_F32_F64, FMA_F32, ADD_U32, CNDMASK_B32, MOV_B32, CMP_F64, MOV_DPP, MBCNT, READLANE,
-          S_ADD_U32, S_MUL_I32, DS_READ_B64, DS_READ_B32, CNDMASK_SGPR, CNDMASK_MIX, CNDMASK_FRESH_VCC, N_OPS };
+          S_ADD_U32, S_MUL_I32, DS_READ_B64, DS_READ_B32, CNDMASK_SGPR, CNDMASK_MIX, CNDMASK_FRESH_VCC,
+          MOV_B64, MIN_U32_DPP, CMP_U32_SGPR, CMP_F64_SGPR, BFE_U32, LSHL_B64, N_OPS };   // (round 6: the last six)
 static const char* kNames[N_OPS] = {"v_fma_f64", "v_add_f64", "v_min_f64", "v_cvt_f32_f64", "v_fma_f32", "v_add_u32", "v_cndmask_b32",
                                     "v_mov_b32", "v_cmp_lt_f64", "v_mov_b32_dpp", "v_mbcnt_lo", "v_readlane_b32", "s_add_u32",
                                     "s_mul_i32", "ds_read_b64", "ds_read_b32", "v_cndmask_e64_sgpr", "v_cndmask+v_add_u32",
-                                    "v_cmp+v_cndmask"};
+                                    "v_cmp+v_cndmask", "v_mov_b64", "v_min_u32_dpp", "v_cmp_lt_u32_e64", "v_cmp_lt_f64_e64", "v_bfe_u32",
+                                    "v_lshlrev_b64"};
 
 // one instruction of class OP on chain j (4 independent chains a[0..3]); inline asm so that the compiler can neither
 // fuse, hoist nor reorder the stream
@@ -52,6 +54,13 @@ __device__ __forceinline__ void one(double (&d)[4], float (&f)[4], unsigned (&u)
         if (j & 1) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(u[j]), "v"(u[(j + 1) & 3]) : "vcc");
         else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(u[(j + 1) & 3]));
     }
+    // round 6: the other classes the persistent kernels' decision loops are made of
+    if constexpr (OP == MOV_B64) asm volatile("v_mov_b64 %0, %1" : "=v"(d[j]) : "v"(d[(j + 1) & 3]), "0"(d[j]));
+    if constexpr (OP == MIN_U32_DPP) asm volatile("v_min_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[j]) : "v"(u[(j + 1) & 3]));
+    if constexpr (OP == CMP_U32_SGPR) { unsigned long long m; asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(u[j]), "v"(u[(j + 1) & 3])); }
+    if constexpr (OP == CMP_F64_SGPR) { unsigned long long m; asm volatile("v_cmp_lt_f64_e64 %0, %1, %2" : "=s"(m) : "v"(d[j]), "v"(d[(j + 1) & 3])); }
+    if constexpr (OP == BFE_U32) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(u[j]));
+    if constexpr (OP == LSHL_B64) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(d[j]));
     if constexpr (OP == DS_READ_B64) asm volatile("ds_read_b64 %0, %1" : "=v"(d[j]) : "v"((unsigned)(threadIdx.x * 8 + j * 512)), "0"(d[j]) : "memory");
     if constexpr (OP == DS_READ_B32) asm volatile("ds_read_b32 %0, %1" : "=v"(u[j]) : "v"((unsigned)(threadIdx.x * 4 + j * 256)), "0"(u[j]) : "memory");
 }
@@ -146,10 +155,20 @@ int main() {
         run<S_MUL_I32, 64>(d_times, d_sink, blocks, n, W);
         run<DS_READ_B64, 64>(d_times, d_sink, blocks, n, W);
         run<DS_READ_B32, 64>(d_times, d_sink, blocks, n, W);
+        run<MOV_B64, 64>(d_times, d_sink, blocks, n, W);
+        run<MIN_U32_DPP, 64>(d_times, d_sink, blocks, n, W);
+        run<CMP_U32_SGPR, 64>(d_times, d_sink, blocks, n, W);
+        run<CMP_F64_SGPR, 64>(d_times, d_sink, blocks, n, W);
+        run<BFE_U32, 64>(d_times, d_sink, blocks, n, W);
+        run<LSHL_B64, 64>(d_times, d_sink, blocks, n, W);
         // the product's occupancy: 4 waves per SIMD (4096 single-wave workgroups)
         run<FMA_F64, 64>(d_times, d_sink, blocks / 2, n, W / 2);
         run<ADD_U32, 64>(d_times, d_sink, blocks / 2, n, W / 2);
         run<S_ADD_U32, 64>(d_times, d_sink, blocks / 2, n, W / 2);
+        run<MOV_B64, 64>(d_times, d_sink, blocks / 2, n, W / 2);
+        run<MOV_DPP, 64>(d_times, d_sink, blocks / 2, n, W / 2);
+        run<READLANE, 64>(d_times, d_sink, blocks / 2, n, W / 2);
+        run<CNDMASK_SGPR, 64>(d_times, d_sink, blocks / 2, n, W / 2);
     }
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     return 0;

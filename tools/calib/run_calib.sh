@@ -23,7 +23,7 @@ for f in glob.glob("gpurun_out/calib/*/**/*counter_collection.csv", recursive=Tr
         agg[(r["Kernel_Name"], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 ops = ["v_fma_f64", "v_add_f64", "v_min_f64", "v_cvt_f32_f64", "v_fma_f32", "v_add_u32", "v_cndmask_b32", "v_mov_b32", "v_cmp_lt_f64",
        "v_mov_b32_dpp", "v_mbcnt_lo", "v_readlane_b32", "s_add_u32", "s_mul_i32", "ds_read_b64", "ds_read_b32", "v_cndmask_e64_sgpr",
-       "v_cndmask+v_add_u32", "v_cmp+v_cndmask"]
+       "v_cndmask+v_add_u32", "v_cmp+v_cndmask", "v_mov_b64", "v_min_u32_dpp", "v_cmp_lt_u32_e64", "v_cmp_lt_f64_e64", "v_bfe_u32", "v_lshlrev_b64"]
 cols = sorted({c for d in agg.values() for c in d})
 with open("gpurun_out/calib/summary.csv", "w") as f:
     f.write("kernel,op,lanes,grid,insts_per_wave," + ",".join(c + "_per_wave_inst" for c in cols) + "\n")

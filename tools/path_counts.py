@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, "dcmrta_amd", "csrc")
 SO = os.path.join(ROOT, "tools", "_variants", "lib_cnt.so")
 NAMES = {0: "decisions", 1: "follower draws", 2: "depot actions", 3: "re-join walks (Q4)", 4: "quiet joins (task_update skipped)",
-         5: "task_update after a join", 6: "task_update calls that remove members", 7: "dropping tasks visited", 8: "group exhausted",
+         5: "task_update after a join", 6: "task_update calls after a join that remove members", 17: "task_update calls at a new event that remove members", 7: "dropping tasks visited", 8: "group exhausted",
          9: "next group of the same event", 10: "next_event (fast)", 12: "events with several deciders", 13: "events with several groups",
          14: "group-split iterations", 15: "general advance() calls", 16: "task_update calls with every task feasible"}
 
