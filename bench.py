@@ -59,7 +59,7 @@ from dcmrta_amd.batched_env import BatchedTaskEnv  # noqa: E402
 from dcmrta_amd.choice import env_seeds  # noqa: E402
 from dcmrta_amd.dist import DistContext, shard_range  # noqa: E402
 from dcmrta_amd.instances import generate_batch, synthetic_route_arrays  # noqa: E402
-from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step, issue_roofline, load_counters,  # noqa: E402
+from dcmrta_amd.roofline import (HBM_PEAK_BYTES_PER_S, algorithmic_bytes_per_step, isa_e32_share, issue_roofline, load_counters,  # noqa: E402
                                  replay_kernel_name, rollout_kernel_name, staleness, step_kernel_name)
 
 REFERENCE_VISIBILITY = (20, 20, 10, 100)      # env/task_env.py:567, :221
@@ -256,7 +256,7 @@ def shard_roofline(kernel, A, T, units_per_pass, pass_s):
     c = load_counters(f"{kernel}:{A}A{T}T")
     if not c:
         return {"kernel": kernel, "frac": None, "note": f"no PMC profile committed for {kernel}:{A}A{T}T"}
-    r = issue_roofline(c, units_per_pass, pass_s, unit="decision")
+    r = issue_roofline(c, units_per_pass, pass_s, unit="decision", e32_share=isa_e32_share(kernel))
     keep = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_hi", "valu_issue_frac", "salu_issue_frac")
             if r.get(k) is not None}
     t = c.get("hbm_bytes_per_decision")
@@ -731,7 +731,7 @@ def main():
         # below); the binding resource is instruction issue.  Instruction counts per step come from the committed rocprofv3
         # PMC profile of this same command, priced per instruction class with the clocks of profiles/r03_calib; decisions and
         # times are live from this run (HIP events on the launch streams).
-        roof.update(issue_roofline(c, dec_per_step, step_s, unit="decision"))
+        roof.update(issue_roofline(c, dec_per_step, step_s, unit="decision", e32_share=isa_e32_share(cfg["kernel"])))
         traffic = c.get("hbm_bytes_per_decision")
         traffic = traffic * dec_per_step if traffic is not None and not args.no_obs else None
         roof.update({"traffic": traffic,

@@ -259,40 +259,6 @@ __device__ __forceinline__ double wave_nanmin_n(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC), hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
     return __hiloint2double(hi, lo);
 }
-// np.nanmin over the wave for values that are all >= +0 or (positive-signed) NaN -- the agents' next_decision times in the kernels
-// the host dispatches for max_waiting_time > 0: for such doubles the order of the 64-bit patterns is the numeric order with NaN on
-// top, so the minimum is an unsigned integer minimum: first over the high words, then over the low words of the lanes that hold the
-// minimal high word.  v_min_u32 takes its DPP operand directly (one instruction per stage; the fp64 form needs two moves, two DPP
-// moves and a v_min_f64 per stage).  Written as asm: hipcc does not fold a DPP move into its user here.  s_nop 1: a VALU write
-// followed by a DPP read of the same register needs two wait states.  All 64 lanes must be active.
-#define DCM_DPP_MIN_U32(v, CTRL) "s_nop 1\n\tv_min_u32_dpp " v ", " v ", " v " " CTRL " bank_mask:0xf\n\t"
-template <int NL>
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
-    static_assert(NL <= 64, "");
-    if constexpr (NL > 32) {
-        asm volatile(DCM_DPP_MIN_U32("%0", "row_shr:1 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:2 row_mask:0xf")
-            DCM_DPP_MIN_U32("%0", "row_shr:4 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:8 row_mask:0xf")
-            DCM_DPP_MIN_U32("%0", "row_bcast:15 row_mask:0xa") DCM_DPP_MIN_U32("%0", "row_bcast:31 row_mask:0xc") : "+v"(x));
-        return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-    } else if constexpr (NL > 16) {
-        asm volatile(DCM_DPP_MIN_U32("%0", "row_shr:1 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:2 row_mask:0xf")
-            DCM_DPP_MIN_U32("%0", "row_shr:4 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:8 row_mask:0xf")
-            DCM_DPP_MIN_U32("%0", "row_bcast:15 row_mask:0xa") : "+v"(x));
-        return (uint32_t)__builtin_amdgcn_readlane((int)x, 31);
-    } else {
-        asm volatile(DCM_DPP_MIN_U32("%0", "row_shr:1 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:2 row_mask:0xf")
-            DCM_DPP_MIN_U32("%0", "row_shr:4 row_mask:0xf") DCM_DPP_MIN_U32("%0", "row_shr:8 row_mask:0xf") : "+v"(x));
-        return (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
-    }
-}
-// lanes NL.. must hold NaN
-template <int NL>
-__device__ __forceinline__ double wave_nanmin_pos(double v) {
-    const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
-    const uint32_t mh = wave_min_u32<NL>(hi);
-    const uint32_t ml = wave_min_u32<NL>(hi == mh ? lo : 0xFFFFFFFFu);
-    return __hiloint2double((int)mh, (int)ml);
-}
 __device__ __forceinline__ double wave_nanmax(double v) {
     v = nanmax2(v, dpp_f64<0x111, 0xF>(v));
     v = nanmax2(v, dpp_f64<0x112, 0xF>(v));

@@ -135,7 +135,6 @@ struct Fast {
         for (int j = 0; j < M; j++) av[j] = S.marr()[j * CT + lt];               // :251 (unused slots hold NaN)
         const double tfin = r.tf, dur = r.dur;
         const int status = req - n;                                              // :252
-#ifdef DCM_TU_SKIP
         // The latest arrival only matters for a task whose coalition is complete (status <= 0 :254): the spread test, time_start and
         // the spread rule's threshold (:255-265).  Such a task exists at the one call after the completing join (or while a stale
         // status lingers, Q3); every other call -- wave-uniform test -- skips the four v_max_f64 and the tests that need them.
@@ -160,18 +159,6 @@ struct Fast {
         const uint64_t bec = __ballot(becomes && inT);
         double nts = r.ts, ntf = tfin;
         if (bec) { nts = becomes ? mx : nts; ntf = becomes ? mx + dur : ntf; }
-#else
-        double mx = av[0], mn = av[0];
-#pragma unroll
-        for (int j = 1; j < M; j++) { mx = nanmax2(mx, av[j]); mn = nanmin2(mn, av[j]); }
-        const bool le0 = status <= 0;                                            // :254
-        const bool ok = le0 && (mx - mn <= mwt);                                 // :255
-        const double thr = mx - mwt;                                             // :262
-        // does any member leave?  (see Sim::task_update: decided on the earliest arrival alone)
-        const bool any_drop = inT && !feas0 && (le0 ? (!ok && mn <= thr) : (now - mn >= mwt));
-        const bool becomes = !feas0 && ok;                                       // :256-258
-        const double nts = becomes ? mx : r.ts, ntf = becomes ? mx + dur : tfin;
-#endif
         int nn = n;
         const uint64_t dmask = __ballot(any_drop);
         if (dmask) {
@@ -249,7 +236,6 @@ struct Fast {
         const uint32_t info_i = ((info | (ok ? T_FEAS : 0u)) & (T_FEAS | T_FIN | 0xFFu)) | ((uint32_t)(status & 0xFF) << 8) | ((uint32_t)nn << 16);
         const uint32_t info_f = info | ((now >= tfin) ? T_FIN : 0u);             // :273-274
         info = feas0 ? info_f : info_i;
-#ifdef DCM_TU_SKIP
         r.ti = info;
         if (inT) S.tinfo()[lt] = info;
         bool over_already = false;
@@ -263,15 +249,6 @@ struct Fast {
         // (see Sim::task_update: a call can only change a task again at the same `now` if this one removed members or made a task
         //  feasible that is already over)
         calm = dmask == 0ull && !over_already;
-#else
-        r.ti = info; r.ts = nts; r.tf = ntf;
-        if (inT) { S.tinfo()[lt] = info; S.ts()[lt] = nts; S.tf()[lt] = ntf; }
-        if constexpr (TRK) { const uint64_t bb = __ballot(becomes && inT); if (bb) { dirty |= SimT::DIRTY_TIMES; dt_times |= bb; } }
-        const bool all_feasible = (__ballot(!(info & T_FEAS)) & tm) == 0ull;
-        // (see Sim::task_update: a call can only change a task again at the same `now` if this one removed members or made a task
-        //  feasible that is already over)
-        calm = dmask == 0ull && __ballot(becomes && inT && now >= ntf) == 0ull;
-#endif
         WSYNC();
         if (all_feasible) {                                                      // depot :277-280
             CNT(16);
@@ -467,11 +444,7 @@ struct Fast {
         FPH(8);
         if (h.now >= P.max_time) return false;
         const double ndv = inA ? r.nd : __builtin_nan("");
-#ifdef DCM_UMIN
-        const double tmin = wave_nanmin_pos<CA>(ndv);                            // :287 (times are never negative here)
-#else
         const double tmin = wave_nanmin_n<CA>(ndv);                              // :287
-#endif
         if (!(tmin == tmin)) return false;
         CNT(10);
         h.now = tmin;                                                            // worker.py:49

@@ -452,11 +452,7 @@ struct FastM {
     __device__ __forceinline__ bool next_event(R& r, HdrRegs& h, const KP& P, int lane) const {
         if (h.now >= P.max_time) return false;
         const double ndv = inA ? r.nd : __builtin_nan("");
-#ifdef DCM_MC_UMIN
-        const double tmin = wave_nanmin_pos<CA>(ndv);                            // :287 (times are never negative here)
-#else
         const double tmin = wave_nanmin(ndv);                                    // :287
-#endif
         if (!(tmin == tmin)) return false;
         h.now = tmin;                                                            // worker.py:49
         const bool dec = (ndv == tmin);                                          // :288 exact ==
@@ -529,10 +525,6 @@ __global__ __launch_bounds__(WAVE, DCM_MC_WAVES) void k_rollout_fast_mc(int A, i
     int left = left0;
     uint64_t gd = h.seed + GAMMA * (h.d + 1);
     const uint64_t d0 = h.d;
-#ifdef DCM_MC_VKEYS
-    uint64_t kv = mix64(gd + GAMMA * (uint64_t)lane);  // the keys of the next 64 decisions, one per lane (see k_rollout_fast)
-    int ki = 0;
-#endif
     typename F::R r;
     f.load_consts(r, xy, lane);
     constexpr uint32_t ERR = DCM_FLAG_BAD_ACTION | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_LEADER | DCM_FLAG_BAD_INSTANCE;
@@ -559,17 +551,10 @@ __global__ __launch_bounds__(WAVE, DCM_MC_WAVES) void k_rollout_fast_mc(int A, i
             WSYNC();
             f.reload(r, lane);
             for (;;) {
-#ifdef DCM_MC_VKEYS
-                const uint64_t k1 = F::rl(kv, ki);
-#else
                 const uint64_t k1 = mix64(gd);
-#endif
                 const int rlen = f.decide(r, h, P, lane, k1, ag, tk, mk);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
-#ifdef DCM_MC_VKEYS
-                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); ki = 0; }
-#endif
                 left--;
                 if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
                     if (h.cur_group < h.n_groups) h.cur_group++;                  // worker.py:52 next group

@@ -8,8 +8,13 @@ INSTRUCTION CLASS with the clocks measured by tools/calib/pmc_calib.hip (profile
 
   * `SQ_ACTIVE_INST_VALU` reads 1.0 per wave64 VALU instruction whatever the instruction costs, so it is an instruction count,
     not a busy time (round 2 priced every instruction at 4 clocks with it);
-  * measured SIMD time per wave64 instruction at 8 waves per SIMD: fp64 arithmetic / compare / convert, DPP moves,
-    v_readlane, v_mbcnt and VOP3 selects with an SGPR mask 4.25 clocks; 32-bit integer / fp32 / moves 2.35 clocks;
+  * measured SIMD time per wave64 instruction at 8 waves per SIMD (profiles/r06_calib): 2.35 clocks for 32-bit VOP1 / VOP2
+    instructions in their e32 encoding (integer add / logic / shift, v_mov_b32, fp32); 4.2-4.3 clocks for everything else -- fp64
+    arithmetic / compare / convert, v_mov_b64, DPP (also folded into a VOP2), v_readlane, v_mbcnt, VOP3 with a scalar mask or
+    destination (v_cndmask_e64, v_cmp_*_e64), v_bfe_u32, v_lshlrev_b64;
+  * which share of a kernel's EXECUTED VALU instructions is in the 2.35 class has no counter: it comes from the ISA
+    (tools/loop_insts.py --phases: the decision loop's instructions classified and weighted with measured trip counts,
+    profiles/r06_budget.md) and is kept in profiles/isa_shares.json;
   * one scalar unit per CU issues 1 SALU instruction per 1.07 clocks (4.27 clocks per SIMD with all four SIMDs issuing).
 """
 import json
@@ -40,7 +45,7 @@ PEAK_CLOCK_HZ = 2.4e9          # peak engine clock (MI355X_MICROARCH.md per-inst
 CLOCKS_VALU_64 = 4.25          # v_fma/add/min/cmp_f64, v_cvt_f32_f64, v_mov_b32_dpp, v_readlane, v_mbcnt, v_cndmask_e64 (SGPR mask)
 CLOCKS_VALU_32 = 2.35          # v_add_u32, v_fma_f32, v_mov_b32
 CLOCKS_SALU_PER_CU = 1.07      # s_add_u32 / s_mul_i32: 4.27 clocks per SIMD-instruction with 4 SIMDs sharing the scalar unit
-CALIB_SOURCE = "profiles/r03_calib/table.txt"
+CALIB_SOURCE = "profiles/r06_calib/table.txt"
 # SQ_INSTS_VALU_* classes that the calibration prices at CLOCKS_VALU_64
 F64_CLASS_COUNTERS = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
                       "SQ_INSTS_VALU_CVT")
@@ -57,29 +62,52 @@ def load_counters(key):
         return None
 
 
-def issue_roofline(c, units_per_step, step_s, unit="decision"):
+_ISA_SHARES = os.path.join(os.path.dirname(_COUNTERS), "isa_shares.json")
+
+
+def isa_e32_share(kernel):
+    """Share of the kernel's executed VALU instructions that are in the 2.35-clock class (profiles/isa_shares.json), or None."""
+    try:
+        with open(_ISA_SHARES) as f:
+            e = json.load(f).get(kernel)
+        return float(e["valu_e32_share"]) if e else None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def issue_roofline(c, units_per_step, step_s, unit="decision", e32_share=None):
     """Issue-bound roofline of a persistent (LDS-resident) kernel from its per-`unit` instruction counters `c`.
 
     VALU pipe time per unit = sum over instruction classes of count x measured clocks.  The class counters cover the fp64
     arithmetic and conversions; the remaining instructions (moves, selects, compares, integer and cross-lane work) are priced
     at the 32-bit rate for `frac` (an estimate that can only be low: part of them are 4-clock instructions) and at the 64-bit
-    rate for `frac_hi` (every VALU instruction at 4.25 clocks -- the upper bound; round 2's figure).  Both are fractions of
+    rate for `frac_hi` (every VALU instruction at 4.25 clocks -- the upper bound; round 2's figure).  With `e32_share` -- the
+    ISA-derived share of executed VALU instructions in the 2.35-clock class (isa_e32_share) -- `frac` prices exactly that share at
+    2.35 and the rest at 4.25: one number instead of a bracket (the class-counter estimate moves to `frac_class_counters`).  Both are fractions of
     1024 SIMDs x 2.4 GHz.  `salu_issue_frac`: scalar-unit issue slots used, 256 CUs x 2.4 GHz / 1.07 clocks per instruction; when
     it exceeds `frac_hi` the scalar unit is the binding resource: `bound` = "salu_issue" and `achieved` / `peak` / `frac` describe
     it (the VALU figures move to `valu_issue_frac` / `valu_issue_frac_hi`)."""
     n_valu = c[f"SQ_INSTS_VALU_per_{unit}"]
     have_classes = all(f"{k}_per_{unit}" in c for k in F64_CLASS_COUNTERS)
     n64 = sum(c[f"{k}_per_{unit}"] for k in F64_CLASS_COUNTERS) if have_classes else 0.0
-    lo = CLOCKS_VALU_64 * n64 + CLOCKS_VALU_32 * (n_valu - n64)
+    lo_counters = CLOCKS_VALU_64 * n64 + CLOCKS_VALU_32 * (n_valu - n64)
     hi = CLOCKS_VALU_64 * n_valu
+    lo = n_valu * (e32_share * CLOCKS_VALU_32 + (1.0 - e32_share) * CLOCKS_VALU_64) if e32_share is not None else lo_counters
     peak = N_SIMD * PEAK_CLOCK_HZ
     per_s = units_per_step / step_s
     out = {"bound": "valu_issue", "achieved": lo * per_s / 1e9, "peak": peak / 1e9, "unit": "G SIMD-clocks/s (VALU pipe busy)",
            "frac": lo * per_s / peak, "frac_hi": hi * per_s / peak,
            "pricing": {"clocks_fp64_class": CLOCKS_VALU_64, "clocks_other": CLOCKS_VALU_32, "fp64_class_insts_per_" + unit: n64,
                        "valu_insts_per_" + unit: n_valu, "class_counters": have_classes, "calibration": CALIB_SOURCE,
-                       "note": "frac prices the fp64-class instructions at 4.25 clocks and all others at 2.35 (low estimate); "
+                       "valu_e32_share_isa": e32_share,
+                       "note": ("frac prices the ISA-derived share of 32-bit e32 instructions at 2.35 clocks and the rest at 4.25 "
+                                "(profiles/isa_shares.json, profiles/r06_budget.md); frac_hi prices every VALU instruction at 4.25; "
+                                "frac_class_counters is the old low estimate (only the fp64 class counters at 4.25)")
+                               if e32_share is not None else
+                               "frac prices the fp64-class instructions at 4.25 clocks and all others at 2.35 (low estimate); "
                                "frac_hi prices every VALU instruction at 4.25"}}
+    if e32_share is not None:
+        out["frac_class_counters"] = lo_counters * per_s / peak
     n_salu = c.get(f"SQ_INSTS_SALU_per_{unit}")
     if n_salu is not None:
         salu = n_salu * CLOCKS_SALU_PER_CU * per_s / (N_CU * PEAK_CLOCK_HZ)

@@ -276,6 +276,13 @@ def test_issue_roofline_pricing():
     assert r["wave_time_split"] == {"executing": 0.4, "parked_on_waitcnt": 0.5, "issue_stalled": 0.1}
     assert r["frac"] <= r["frac_hi"] and r["pricing"]["class_counters"] is True and r["bound"] == "valu_issue"
     assert R.staleness(c, "abc") is False and R.staleness(c, "abd") is True and R.staleness({}, "abc") is True
+    # with the ISA-derived share of 2.35-clock instructions `frac` is that exact mix; the class-counter estimate stays on record
+    r1 = R.issue_roofline(c, 1e6, 1e-3, e32_share=0.25)
+    assert abs(r1["frac"] - 100 * (0.25 * 2.35 + 0.75 * 4.25) * 1e9 / (1024 * 2.4e9)) < 1e-12 and r1["frac_hi"] == r["frac_hi"]
+    assert abs(r1["frac_class_counters"] - r["frac"]) < 1e-15 and r1["pricing"]["valu_e32_share_isa"] == 0.25
+    assert abs(r1["frac"] - r1["achieved"] / r1["peak"]) < 1e-12 and r["frac"] < r1["frac"] < r1["frac_hi"]
+    sh = R.isa_e32_share("k_rollout_fast")
+    assert sh is not None and 0.1 < sh < 0.5 and R.isa_e32_share("no_such_kernel") is None
     del c["SQ_INSTS_VALU_CVT_per_decision"]                            # no class counters: every instruction at the 32-bit rate
     r2 = R.issue_roofline(c, 1e6, 1e-3)
     assert r2["pricing"]["class_counters"] is False and abs(r2["frac"] - 235 * 1e9 / (1024 * 2.4e9)) < 1e-12
