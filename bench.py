@@ -197,6 +197,27 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
            "rocprof_avg_launch_us": c.get("avg_launch_us") if c else None, "empty_event_pair_us": bracket_us,
            "stale": staleness(c, _lib.build_id()) if c else None}
     env.close()
+    # ... and the BASELINE batch in the steady state of a collection loop (DCM_PARAM_AUTO_RESET, the first 150 steps untimed): every
+    # launch then holds envs whose episode ends in it -- terminal metrics, restart, first event: the launch's slowest waves
+    # (tools/lockstep_probe.py 4096 A T 200 steady measures the same)
+    try:
+        Bs = 4096
+        env = BatchedTaskEnv(Bs, A, T, device=str(dev), auto_reset=True).load_instances(**generate_batch(Bs, A, T, base_seed=0))
+        obs = env.reset(env_seeds(0, 0, Bs))
+        for _ in range(150):
+            obs = env.step(torch.multinomial((~obs.mask).float(), 1).squeeze(1).int())
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        for a, b in ev:
+            act = torch.multinomial((~obs.mask).float(), 1).squeeze(1).int()
+            a.record()
+            obs = env.step(act)
+            b.record()
+        torch.cuda.synchronize(dev)
+        out["steady_state_us"] = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2] * 1e3
+        out["steady_state_envs"] = Bs
+        env.close()
+    except Exception as ex:
+        out["steady_state_error"] = f"{type(ex).__name__}: {ex}"[:200]
     return out
 
 
