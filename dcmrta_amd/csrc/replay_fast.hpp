@@ -311,9 +311,11 @@ __global__ __launch_bounds__(WAVE, DCM_REPLAY_WAVES) void k_replay_fast(int A, i
                 // (the entry behind the cursor, for the pop below: requested now, a whole distance chain before it is used)
                 const int h1_l = head_l + 1;
                 const int up_l = lroute[(i * WAVE + lane < A ? i * WAVE + lane : 0) * route_cap + (h1_l < route_cap ? h1_l : 0)];
-                const int action = rli(pop_l ? nxt[i] : 0, l);
+                int action = rli(pop_l ? nxt[i] : 0, l);
                 const bool popped = (__ballot(pop_l) >> l) & 1ull;
-                if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; break; }
+                // (no exit from the middle of a step -- it would keep a second copy of every lane-owned field alive across the step,
+                //  see Fast::decide: the env is flagged, the step runs as a depot visit and the loop ends at the test below the step)
+                if (action < 0 || action > T) { flags |= DCM_FLAG_BAD_ACTION; action = 0; }
                 const int k = action - 1, kk = k >= 0 ? k : 0, kl = kk & 63, kc = k >= 0 ? (k >> 6) : -1;
                 // agent_step :300-324.  One LDS round trip: the task's location and member ids (wave-uniform address).  The distance
                 // chain runs on all lanes (each from its own position: fp64 VALU work with fewer than 16 active lanes is 4x slower
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(WAVE, DCM_REPLAY_WAVES) void k_replay_fast(int A, i
                 }
                 if constexpr (REACTIVE) { if (tu_changed) recount_visible(); }
                 agent_update((was_redo || tu_changed) ? ALL_AGENTS : (1u << i));      // :576/:583/:587
-                if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW)) break;
+                if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
             }
             if (flags & (R_TYPE_ERROR | DCM_FLAG_OVERFLOW | DCM_FLAG_BAD_ACTION)) break;
         }
