@@ -552,7 +552,14 @@ struct Sim {
         const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
         uint4 row{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};       // this lane's agent: its first eight abandonment entries
-        if (gather && lane < A_) row = *(const uint4*)(ablog() + lane * AB_CAP);
+        if (gather && lane < A_) {
+            // (agent-scope loads, past the CU's vector L1: the row was written by this wave's own removal path, possibly after an
+            //  earlier terminal call of the same launch had read -- and cached -- the line; the same rule as replay_fast.hpp's gload)
+            const unsigned long long* q = (const unsigned long long*)(ablog() + lane * AB_CAP);
+            const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            row = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        }
         for (int i = lane; i < A_ * TW; i += WAVE) amask()[i] = 0ull;         // per agent: bitmask of the tasks listing it
         WSYNC();
         for_tasks(lane, [&](int t) {

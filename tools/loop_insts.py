@@ -91,8 +91,11 @@ def main():
         body = open(out).read().splitlines()
     # the body of the instantiated kernel only (the TU also holds the non-template helper kernels)
     base = re.match(r"\w+", kernel).group(0)
-    starts = [i for i, l in enumerate(body) if re.match(r"^_Z\w*" + re.escape(f"{len(base)}{base}") + r"\w*:\s+; @", l)]
-    ends = [i for i, l in enumerate(body) if l.startswith("\t.amdhsa_kernel ") and base in l]
+    targs = re.search(r"<(.*)>", kernel).group(1).split(",")
+    mangled = f"{len(base)}{base}I" + "".join(f"Lb{int(a.strip() == 'true')}E" if a.strip() in ("true", "false") else f"Li{int(a)}E"
+                                               for a in targs) + "E"
+    starts = [i for i, l in enumerate(body) if re.match(r"^_Z\w*" + re.escape(mangled) + r"\w*:\s+; @", l)]
+    ends = [i for i, l in enumerate(body) if l.startswith("\t.amdhsa_kernel ") and mangled in l]
     body = body[starts[-1]:ends[-1]]
     rem = rem[rem.rfind("Function Name: " + body[0].split(":")[0]):]
     rem = "\n".join(rem.splitlines()[:12])                      # (the remarks of this function only)
