@@ -50,7 +50,8 @@ __host__ __device__ inline uint32_t replay_fast_lds_bytes(int A, int T, int rout
 }
 
 #ifndef DCM_REPLAY_WAVES
-#define DCM_REPLAY_WAVES 1      // minimum waves per SIMD asked of the compiler for k_replay_fast (155 VGPRs = three on its own; asking for four spills: slower)
+#define DCM_REPLAY_WAVES 1      // minimum waves per SIMD asked of the compiler for k_replay_fast (133 VGPRs = three on its own since the step has no
+                                // exit in its middle -- round 6; four fit without spills, 128 VGPRs, and measure the same: 2.01e9 both ways)
 #endif
 
 template <int NAC, int NTL, int CMR, bool REACTIVE>

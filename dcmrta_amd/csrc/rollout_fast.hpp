@@ -24,6 +24,11 @@
 // Everything that happens once per episode or less -- reset, the terminal metrics, events at which nobody can decide, the first
 // event of an episode -- runs the verified Sim<> code on the LDS image: the fast path flushes its registers, calls it, reloads.
 //
+// Round 6 (profiles/r06_budget.md): the kernel is bound by the length of ONE wave's instruction stream (a lone wave needs 0.78 ms of
+// the 1.24 ms a 4096-env launch takes), so the stream itself was cut: the choice-protocol keys of 64 decisions are computed one per
+// lane; decide() has no exit in its middle (an exit there keeps a second copy of all 15 lane-owned fields alive: 15 v_mov per
+// decision); task_update touches the latest arrival / time_start only when a coalition is complete / a task becomes feasible.
+//
 // Reference restated: worker.py:45-87 (loop), env/task_env.py:161-342 (the functions named at each block below).
 #pragma once
 #include <type_traits>
@@ -311,11 +316,9 @@ struct Fast {
         if (glen == 0) return -1;
         return nth(gm, below((uint32_t)(k1 >> 32), glen));
     }
-    // UPD = false: without the closing task_update / agent_update (the caller runs them; `quiet_out` = the task_update can be skipped)
-    template <bool UPD = true>
     // k2p: the decision's second key mix64(k1 + GAMMA) (the first two follower draws) if the caller has it, else nullptr
     __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp,
-                                          bool* quiet_out = nullptr, const uint64_t* k2p = nullptr) const {
+                                          const uint64_t* k2p = nullptr) const {
         uint64_t gm;
         // (no early return: an exit from the middle of a decision would keep the whole register set of the agent / task state alive
         //  in a second copy -- 15 v_mov per decision at the loop latch.  An empty group is unreachable; if it ever happened the env
@@ -329,12 +332,11 @@ struct Fast {
         const int nv = __popcll(bm);
         const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
         FPH(2);
-        return apply<UPD>(r, h, P, lane, k1, gm, leader, action, quiet_out, k2p);
+        return apply(r, h, P, lane, k1, gm, leader, action, k2p);
     }
     // TaskEnv.step :326-342 with the leader's (valid: unmasked task or depot) action, then task_update / agent_update
-    template <bool UPD = true>
     __device__ __forceinline__ int apply(R& r, const HdrRegs& h, const KP& P, int lane, uint64_t k1, uint64_t gm, int leader, int action,
-                                         bool* quiet_out = nullptr, const uint64_t* k2p = nullptr) const {
+                                         const uint64_t* k2p = nullptr) const {
         const double now = h.now;
         uint64_t rest = gm & ~(1ull << leader);                                  // :328
         int rlen = __popcll(gm) - 1;
@@ -426,12 +428,10 @@ struct Fast {
         }
         WSYNC();
         FPH(5);
-        if constexpr (UPD) {
-            if (!quiet) { CNT(5); task_update(r, now, P.mwt, lane); } else CNT(4);     // worker.py:74
-            FPH(6);
-            agent_update(r, now, P.mwt);                                             // worker.py:76
-            FPH(7);
-        } else *quiet_out = quiet;
+        if (!quiet) { CNT(5); task_update(r, now, P.mwt, lane); } else CNT(4);         // worker.py:74
+        FPH(6);
+        agent_update(r, now, P.mwt);                                                 // worker.py:76
+        FPH(7);
         return rlen;
     }
 
@@ -439,7 +439,6 @@ struct Fast {
     // Boxes D + A of the loop when somebody can decide and MAX_TIME has not passed: next_decision (env/task_env.py:283-289),
     // get_unique_group (:291-298), task_update, agent_update (worker.py:49-51).  Returns false -- with nothing changed -- when the
     // event needs the general code (nobody can decide: check_finished :366-373; or the loop test of worker.py:45 ends the episode).
-    template <bool UPD = true>
     __device__ __forceinline__ bool next_event(R& r, HdrRegs& h, const KP& P, int lane) const {
         FPH(8);
         if (h.now >= P.max_time) return false;
@@ -478,12 +477,10 @@ struct Fast {
             h.n_groups = g;
         }
         FPH(9);
-        if constexpr (UPD) {
-            task_update(r, tmin, P.mwt, lane, 11);                                   // worker.py:50
-            FPH(10);
-            agent_update(r, tmin, P.mwt);                                            // worker.py:51
-            FPH(11);
-        }
+        task_update(r, tmin, P.mwt, lane, 11);                                       // worker.py:50
+        FPH(10);
+        agent_update(r, tmin, P.mwt);                                                // worker.py:51
+        FPH(11);
         h.empty_passes = 0;
         h.cur_group = 1;
         return true;
@@ -571,7 +568,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
                 FPHK(f, 12);
                 CNT(0);
                 const uint64_t k1 = F::rl(kv, ki), k2 = F::rl(kv2, ki);
-                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, nullptr, &k2);
+                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, &k2);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
                 if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; }
