@@ -429,4 +429,23 @@ struct dcm_env {
     dcm::RouteLog log{nullptr, nullptr, nullptr, 0};   // dcm_set_route_log
     double* retlog = nullptr;        // dcm_set_return_log: [B][retcap] ring of episode returns
     int32_t retcap = 0;
+    // Deferred terminal metrics of the lockstep API (step_fast.hpp: dcm_step with DCM_PARAM_AUTO_RESET on a one-chunk layout): the wave
+    // that ends an episode parks the final record here instead of running calculate_waiting_time itself -- it is the slowest wave of
+    // its launch -- and k_terminal_flush computes reward + metrics from the snapshots later (every FLUSH_EVERY steps, and before
+    // anything reads or writes the summary rows)
+    unsigned char* side = nullptr;   // [B][side_pitch]: record image + the env's abandonment rows at the end of the episode
+    uint32_t* pendq = nullptr;       // [0] number of snapshots waiting, [1 .. B] their envs, [1 + B .. 2 B] per-env state (0 / 1 waiting / 2 queued, superseded)
+    uint32_t side_pitch = 0;
+    int steps_since_flush = 0;
+    bool maybe_pending = false, side_failed = false;
+    bool captured = false;           // a dcm_step of this handle was captured into a graph: every later step computes its metrics inline
+    static constexpr int FLUSH_EVERY = 32;
 };
+
+namespace dcm {
+// compute the summary rows of the snapshots that are waiting (no-op when none can be); every entry point that reads or writes
+// summary rows calls it first
+int flush_pending(dcm_env* env, void* stream);
+// forget them (the envs are being reset / reloaded)
+int drop_pending(dcm_env* env, void* stream);
+}  // namespace dcm

@@ -855,6 +855,21 @@ struct Sim {
         h.cur_group = 0;
     }
 
+    // What terminal() does without the metrics (k_step_fast with a snapshot buffer, see dcm_env::side): the caller parks the record,
+    // k_terminal_flush computes reward + metrics from it later.  The informational WAIT_ORDER flag is not kept: the env restarts
+    // in this very launch, which clears the flags anyway.
+    static constexpr uint32_t FLAG_DEFERRED = 1u << 30;      // internal, never stored in a record
+    __device__ __forceinline__ void terminal_deferred(HdrRegs& h, int lane) const {
+        h.flags |= DCM_FLAG_DONE | FLAG_DEFERRED;
+        if (lane == 0) {
+            const uint32_t n = ((Hdr*)base)->episodes;
+            ((Hdr*)base)->episodes = n + 1;
+            double* ring = *(double* const*)(base + aux_off() + 32);          // dcm_set_return_log
+            if (ring) ring[n % (uint32_t)*(const int32_t*)(base + aux_off() + 40)] = -h.now;   // reward, env/task_env.py:424
+        }
+        h.cur_group = 0;
+    }
+
     // ------------------------------------------------------------------------------ event loop
     // Boxes D + A of SURVEY.md Appendix B: check_finished (worker.py:85, env/task_env.py:366-373), loop test
     // (worker.py:45), next_decision (:283-289), get_unique_group (:291-298), task_update, agent_update
@@ -862,7 +877,7 @@ struct Sim {
     // no_grouping: every deciding agent forms ONE group (individual selection, worker.py:159-198 iterates the deciders without
     // get_unique_group); lockstep API only.
     __device__ __forceinline__ void advance(HdrRegs& h, const KP& P, int lane, double* __restrict__ row PH_ARGS,
-                                            bool no_grouping = false, bool track = false) const {
+                                            bool no_grouping = false, bool track = false, bool defer = false) const {
         const int A_ = A();
         for (;;) {
             WSYNC();
@@ -896,7 +911,10 @@ struct Sim {
                 finished = __all(allret) && __all(allfin);                   // :370
             }
             if (finished) h.flags |= DCM_FLAG_FINISHED;
-            if (finished || h.now >= P.max_time) { terminal(h, P, lane, row); return; }   // worker.py:45
+            if (finished || h.now >= P.max_time) {                           // worker.py:45
+                if (defer) terminal_deferred(h, lane); else terminal(h, P, lane, row);
+                return;
+            }
             // ---- A: new event
             h.n_groups = 0;
             if (any) {
@@ -969,7 +987,11 @@ struct Sim {
             agent_update(h, P, lane);                                         // worker.py:51
             PH_MARK(8);
             if (!any) {
-                if (++h.empty_passes > 4) { h.flags |= DCM_FLAG_TRUNCATED; terminal(h, P, lane, row); return; }
+                if (++h.empty_passes > 4) {
+                    h.flags |= DCM_FLAG_TRUNCATED;
+                    if (defer) terminal_deferred(h, lane); else terminal(h, P, lane, row);
+                    return;
+                }
                 continue;
             }
             h.empty_passes = 0;
@@ -1939,6 +1961,8 @@ int dcm_destroy(dcm_env* env) {
     if (env->route_len) (void)hipFree(env->route_len);
     if (env->rmarr) (void)hipFree(env->rmarr);
     if (env->sizes) (void)hipFree(env->sizes);
+    if (env->side) (void)hipFree(env->side);
+    if (env->pendq) (void)hipFree(env->pendq);
     delete env;
     return DCM_OK;
 }
@@ -1948,6 +1972,7 @@ int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy,
                        void* stream) {
     CHECK_ENV(env);
     if (!depot || !task_xy || !req || !dur) return fail(DCM_ERR_INVALID, "dcm_load_instances: null array");
+    { const int rc_ = dcm::drop_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     if (env->sizes) { HIP_TRY(hipFree(env->sizes)); env->sizes = nullptr; }   // back to a uniform batch (hipFree synchronises)
     hipLaunchKernelGGL(k_load_instances, GRID(env), 0, (hipStream_t)stream, DIMS(env), env->L.C, env->state, depot, task_xy,
                        req, dur, (const int32_t*)nullptr);
@@ -1960,6 +1985,7 @@ int dcm_load_instances(dcm_env* env, const double* depot, const double* task_xy,
 int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* task_xy, const int32_t* req,
                               const double* dur, const int32_t* n_agents_host, const int32_t* n_tasks_host, void* stream) {
     CHECK_ENV(env);
+    { const int rc_ = dcm::drop_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     if (!depot || !task_xy || !req || !dur || !n_agents_host || !n_tasks_host)
         return fail(DCM_ERR_INVALID, "dcm_load_instances_ragged: null array");
     const int B = env->p.n_envs;
@@ -1981,8 +2007,41 @@ int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* t
     return DCM_OK;
 }
 
+}  // extern "C"
+
+namespace dcm {
+int flush_pending(dcm_env* env, void* stream) {
+    if (!env->maybe_pending) return DCM_OK;
+    const unsigned grid = (unsigned)(env->p.n_envs < 512 ? env->p.n_envs : 512);
+#define CALL(CA, CT, RS)                                                                                             \
+    hipLaunchKernelGGL((k_terminal_flush<CA, CT, RS>), dim3(grid), dim3(dcm::WAVE),                                    \
+                       (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u + (step_scratch_in_lds<CA, CT>() ? env->L.scratch_bytes() : 0u), \
+                       (hipStream_t)stream, DIMS(env), env->kp, (const unsigned char*)env->side, env->side_pitch, env->pendq,       \
+                       (uint32_t)env->p.n_envs, env->summary, (const int32_t*)env->sizes, env->gscratch)
+    const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
+    if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
+    else { CALL(64, 64, true); }
+#undef CALL
+    LAUNCH_OK();
+    HIP_TRY(hipMemsetAsync(env->pendq, 0, sizeof(uint32_t), (hipStream_t)stream));     // the count; the kernel cleared the envs' flags
+    env->maybe_pending = false;
+    env->steps_since_flush = 0;
+    return DCM_OK;
+}
+int drop_pending(dcm_env* env, void* stream) {
+    if (!env->maybe_pending) return DCM_OK;
+    HIP_TRY(hipMemsetAsync(env->pendq, 0, (size_t)(1 + 2 * (size_t)env->p.n_envs) * sizeof(uint32_t), (hipStream_t)stream));
+    env->maybe_pending = false;
+    env->steps_since_flush = 0;
+    return DCM_OK;
+}
+}  // namespace dcm
+
+extern "C" {
+
 int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     CHECK_ENV(env);
+    { const int rc_ = dcm::drop_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_reset: call dcm_load_instances first");
     if (!seeds) return fail(DCM_ERR_INVALID, "dcm_reset: null seeds");
 #define CALL(CA, CT, RS, ...)                                                                                         \
@@ -2044,20 +2103,52 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
     // The plain call shape on a one-chunk layout: the register-resident step (step_fast.hpp); same contract, same results.
     if (quiet_ok && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && !leader_in && !nfol_in && !env->log.len && agents_out && tasks_out &&
         mask_out && leader_out && active_out && !(env->p.flags & DCM_PARAM_NO_GROUPING)) {
+        // Deferred terminal metrics (dcm_env::side) for auto-resetting handles: not under stream capture -- the periodic flush is a
+        // host-side decision and the buffers are allocated on first use -- where episode ends keep computing their metrics inline.
+        uint32_t* pendq = nullptr;
+        if (env->p.flags & DCM_PARAM_AUTO_RESET) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+            if (capturing) {
+                if (env->maybe_pending)
+                    return fail(DCM_ERR_STATE, "dcm_step under stream capture: deferred episode summaries are waiting; call dcm_summary (or dcm_reset) before the capture");
+                env->captured = true;      // a replay of this graph writes summary rows unseen by the host: no snapshots on this handle any more
+            } else if (!env->captured) {
+                if (!env->side && !env->side_failed) {
+                    const uint32_t pitch = dcm::align16(env->L.rec_bytes() + (uint32_t)env->L.A * dcm::AB_CAP * (uint32_t)sizeof(uint16_t));
+                    const size_t qn = 1 + 2 * (size_t)env->p.n_envs;
+                    if (hipMalloc((void**)&env->side, (size_t)env->p.n_envs * pitch) != hipSuccess ||
+                        hipMalloc((void**)&env->pendq, qn * sizeof(uint32_t)) != hipSuccess ||
+                        hipMemset(env->pendq, 0, qn * sizeof(uint32_t)) != hipSuccess) {
+                        (void)hipGetLastError();                         // out of memory: keep the inline terminal metrics
+                        if (env->side) { (void)hipFree(env->side); env->side = nullptr; }
+                        if (env->pendq) { (void)hipFree(env->pendq); env->pendq = nullptr; }
+                        env->side_failed = true;
+                    } else env->side_pitch = pitch;
+                }
+                pendq = env->pendq;
+            }
+        }
 #define CALL(CA, CT, RS)                                                                                             \
     hipLaunchKernelGGL((k_step_fast<CA, CT, RS>), GRID(env),                                                           \
                        (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u + (step_scratch_in_lds<CA, CT>() ? env->L.scratch_bytes() : 0u), \
                        (hipStream_t)stream, DIMS(env), env->kp,                                                            \
                        env->state, actions, agents_out, tasks_out, mask_out, leader_out, active_out, env->summary, env->ablog,  \
-                       env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap)
+                       env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap, \
+                       env->side, env->side_pitch, pendq)
         const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
         if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
         else { CALL(64, 64, true); }
 #undef CALL
         LAUNCH_OK();
+        if (pendq) {
+            env->maybe_pending = true;
+            if (++env->steps_since_flush >= dcm_env::FLUSH_EVERY) return dcm::flush_pending(env, stream);
+        }
         return DCM_OK;
     }
 #endif
+    { const int rc_ = dcm::flush_pending(env, stream); if (rc_ != DCM_OK) return rc_; }    // (the general kernel writes summary rows itself)
 #define CALL(CA, CT, RS, ...)                                                                                        \
     hipLaunchKernelGGL((k_step<CA, CT, RS, ##__VA_ARGS__>), GRID(env), (Sim<CA, CT, RS>::lds_image_bytes(env->L)), (hipStream_t)stream, DIMS(env), env->kp,   \
                        env->state, actions, leader_in, nfol_in, followers_in, agents_out, tasks_out, mask_out, leader_out, \
@@ -2074,6 +2165,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     CHECK_ENV(env);
     if (!env->reset_done) return fail(DCM_ERR_STATE, "dcm_rollout_random: call dcm_reset first");
     if (episodes < 1) return fail(DCM_ERR_INVALID, "dcm_rollout_random: episodes must be >= 1");
+    { const int rc_ = dcm::flush_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     const bool quiet_ok = env->kp.mwt > 0.0;     // (see dcm_step)
 #ifndef DCM_NO_FAST_ROLLOUT
     // One-chunk layouts (one lane per agent and per task, lane 63 free for the depot) with all three observation buffers or
@@ -2130,6 +2222,7 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
 int dcm_summary(dcm_env* env, double* out, void* stream) {
     CHECK_ENV(env);
     if (!out) return fail(DCM_ERR_INVALID, "dcm_summary: null out");
+    { const int rc_ = dcm::flush_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     HIP_TRY(hipMemcpyAsync(out, env->summary, (size_t)env->p.n_envs * 8 * sizeof(double), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
     return DCM_OK;
@@ -2209,6 +2302,7 @@ int dcm_state_bytes(dcm_env* env, size_t* bytes_out) {
 int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
     CHECK_ENV(env);
     if (!dst) return fail(DCM_ERR_INVALID, "dcm_clone_state: null dst");
+    { const int rc_ = dcm::flush_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(dst, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);
@@ -2221,6 +2315,7 @@ int dcm_clone_state(dcm_env* env, void* dst, void* stream) {
 int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
     CHECK_ENV(env);
     if (!src) return fail(DCM_ERR_INVALID, "dcm_restore_state: null src");
+    { const int rc_ = dcm::drop_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
     HIP_TRY(hipMemcpyAsync(env->state, src, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     const size_t mb = (size_t)env->p.n_envs * 8 * sizeof(double);

@@ -807,6 +807,7 @@ int dcm_execute_routes(dcm_env* env, int32_t reactive, int64_t* steps_out, uint3
                        double* time_start, double* time_finish, double* task_wait, int32_t* n_members,
                        double* agent_wait, double* travel_dist, uint8_t* returned, void* stream) {
     CHECK_ENV(env);
+    { const int rc_ = dcm::flush_pending(env, stream); if (rc_ != DCM_OK) return rc_; }
     if (!env->loaded) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_instances first");
     if (!env->routes) return fail(DCM_ERR_STATE, "dcm_execute_routes: call dcm_load_routes first");
     if (env->sizes) return fail(DCM_ERR_STATE, "dcm_execute_routes: route replay needs a uniform batch (dcm_load_instances)");

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
                                                    float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
                                                    uint8_t* active_out, double* summary, uint16_t* ablog, uint32_t mode,
                                                    const int32_t* sizes, unsigned char* gscr, uint32_t max_episodes, double* retlog,
-                                                   int retcap) {
+                                                   int retcap, unsigned char* side, uint32_t side_pitch, uint32_t* pendq) {
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
@@ -185,7 +185,21 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
             // its 128-VGPR limit with 40 B of spills, some of them on the common path.  Two tails: 105 VGPRs, no spills of its own.
             if (plain) {
                 f.flush(r);
-                S.advance(h, P, lane, row PH_PASS, false, true);
+                // Deferred terminal metrics (pendq != nullptr, see dcm_env::side): if this event ends the episode and the env restarts
+                // right away, the wave only parks the final record; calculate_waiting_time -- 6-7 us of this wave's 13-15, and this
+                // wave is what a 4096-env launch waits for: 23.8 -> 15.9 us per step without it -- runs in k_terminal_flush later.
+                // Not when an abandonment log overflowed into the count table (the restart clears it).  An env whose previous snapshot
+                // is still waiting overwrites it: the summary row holds the LAST finished episode, the return log has the older one.
+                bool defer = false;
+                if (pendq && (mode & DCM_PARAM_AUTO_RESET)) {
+                    const uint32_t ep = uni(((const Hdr*)smem)->episodes);
+                    if (max_episodes == 0 || ep + 1 < max_episodes) {
+                        bool spilled = false;
+                        S.for_agents(lane, [&](int a) { spilled = spilled || (S.ainfo()[a] >> 16) > (uint32_t)AB_CAP; });
+                        defer = !__any(spilled);
+                    }
+                }
+                S.advance(h, P, lane, row PH_PASS, false, true, defer);
             } else {
                 // masked / out-of-range action: simulated (or refused, DCM_PARAM_STRICT_MASK) by the general code, see apply_and_advance
                 AMask gm;
@@ -196,6 +210,28 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
             }
             h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
             h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
+            if (h.flags & SimT::FLAG_DEFERRED) {
+                // park the record (the LDS image is current: an episode only ever ends in the general code), the final time and the
+                // env's abandonment rows (its own earlier stores: agent-scope loads, past the CU's vector L1), then announce it
+                h.flags &= ~SimT::FLAG_DEFERRED;
+                unsigned char* sp = side + (size_t)e * side_pitch;
+                WSYNC();
+                copy16(sp, smem, L.rec_bytes(), lane);
+                const unsigned long long* src = (const unsigned long long*)S.ablog();
+                unsigned long long* dst = (unsigned long long*)(sp + L.rec_bytes());
+                for (int i = lane; i < S.A() * (AB_CAP / 4); i += WAVE) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    ((Hdr*)sp)->now = h.now;          // (after lane 0's own copy of the header piece: same lane, same address, in order)
+                    uint32_t* const st = &pendq[1u + gridDim.x + (uint32_t)e];      // 0 not queued, 1 snapshot waiting, 2 queued but stale
+                    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) pendq[1u + atomicAdd(&pendq[0], 1u)] = (uint32_t)e;
+                    *st = 1u;
+                }
+            } else if (pendq && (h.flags & DCM_FLAG_DONE) && lane == 0) {
+                // the episode ended with its metrics computed here (masked action, overflowed log, last episode of the handle's budget):
+                // a snapshot of an earlier episode must not overwrite the row later
+                uint32_t* const st = &pendq[1u + gridDim.x + (uint32_t)e];
+                if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) *st = 2u;
+            }
             // DCM_PARAM_AUTO_RESET: the episode has just ended -> start the next one from the loaded instance (see k_step); an episode
             // only ever ends in the general code, so the LDS image is current here
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) && !(h.flags & ERR) &&
@@ -214,4 +250,39 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
         h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
     }
     finish(regs);
+}
+
+
+// Reward + perf metrics (env/task_env.py:344-364,420-425, worker.py:103-108) of the episodes whose final records k_step_fast parked
+// (dcm_env::side): workgroup i takes snapshots i, i + gridDim.x, ...; the host clears the count behind the launch (same stream).
+template <int CA, int CT, bool RS>
+__global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_terminal_flush(int A, int T, int PA, int PT, KP P, const unsigned char* side, uint32_t side_pitch,
+                                                        uint32_t* pendq, uint32_t B, double* summary, const int32_t* sizes, unsigned char* gscr) {
+    const int lane = threadIdx.x;
+    using SimT = Sim<CA, CT, RS, false>;
+    const uint32_t n = uni(pendq[0]);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int e = (int)uni(pendq[1u + i]);
+        if (uni(pendq[1u + B + (uint32_t)e]) != 1u) {            // a later episode's row was computed by the step kernel itself
+            if (lane == 0) pendq[1u + B + (uint32_t)e] = 0u;
+            continue;
+        }
+        int eA, eT;
+        env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
+        SimT S{eA, eT, PA, PT, smem, nullptr};
+        const Lay L = S.L();
+        S.scr = step_scratch_in_lds<CA, CT>() ? smem + SimT::lds_image_bytes(L) + 512u : gscr + (size_t)e * L.scratch_bytes();
+        const unsigned char* sp = side + (size_t)e * side_pitch;
+        WSYNC();                                                 // (the previous snapshot's LDS reads are done)
+        copy16_in(smem, sp, L.rec_bytes(), lane);
+        if (lane == 0) {                                         // the image's pointers: this snapshot's abandonment rows, nothing else
+            *(const uint16_t**)(smem + S.aux_off()) = (const uint16_t*)(sp + L.rec_bytes());
+            *(uint8_t**)(smem + S.aux_off() + 16) = nullptr;     // (a log that overflowed into the count table is never deferred)
+            *(double**)(smem + S.aux_off() + 32) = nullptr;
+        }
+        WSYNC();
+        const double now = uni(((const Hdr*)smem)->now);
+        (void)SimT::terminal_metrics(S, now, P.mwt, lane, summary + (size_t)e * 8);
+        if (lane == 0) pendq[1u + B + (uint32_t)e] = 0u;
+    }
 }

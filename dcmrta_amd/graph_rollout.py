@@ -108,6 +108,9 @@ class GraphedRollout:
                 for _ in range(self._warmup):
                     obs = self._one_step(obs, n)
             torch.cuda.current_stream(env.device).wait_stream(s)
+            # (an auto-resetting handle defers the terminal metrics of its eager steps -- the warm-up above -- and refuses a capture
+            #  while such summaries are waiting: dcm_summary computes them)
+            env.summary()
             torch.cuda.synchronize(env.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -78,7 +78,14 @@ typedef enum {
  * fused observation is the first decision of the new episode; the env stays active.  dcm_env_episodes counts the finished
  * episodes.  This is SURVEY.md §8(d)'s "consecutive episodes, auto-reset to the same instance" for a policy in the loop: the
  * batch stays full instead of waiting for its longest episode.  Envs frozen by an error flag are not restarted, nor envs
- * that have finished dcm_params.auto_reset_episodes episodes (when that is non-zero). */
+ * that have finished dcm_params.auto_reset_episodes episodes (when that is non-zero).
+ * The summary row of an episode that ended in an eager dcm_step may be computed LAZILY (the wave that ends an episode is the slowest
+ * of its launch: it parks the final record and the reward + metrics are computed from it later, in batches): dcm_summary -- like
+ * every entry point that reads or writes summary rows -- completes the waiting rows first, on the stream it is given, so callers
+ * see no difference; the return log (dcm_set_return_log) and dcm_env_episodes are always up to date.  A dcm_step issued under
+ * stream capture computes its terminal metrics inline and refuses (DCM_ERR_STATE) to be captured while rows of earlier eager steps
+ * are still waiting: call dcm_summary or dcm_reset before the capture.  After a capture every step of the handle, eager or replayed,
+ * computes its metrics inline. */
 #define DCM_PARAM_AUTO_RESET 2u
 /* dcm_params.flags: refuse host-supplied actions on masked tasks.  By default dcm_step simulates ANY action in [0, T] the way
  * TaskEnv.step does (env/task_env.py:326-342 never looks at the mask; worker.py:140's argmax can return a masked index): on a
