@@ -213,7 +213,10 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
             obs = env.step(act)
             b.record()
         torch.cuda.synchronize(dev)
-        out["steady_state_us"] = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2] * 1e3
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        out["steady_state_us"] = us[len(us) // 2]
+        # (with deferred terminal metrics one dcm_step in 32 also launches k_terminal_flush: in the mean, not in the median)
+        out["steady_state_mean_us"] = sum(us) / len(us)
         out["steady_state_envs"] = Bs
         env.close()
     except Exception as ex:

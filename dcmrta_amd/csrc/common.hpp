@@ -434,8 +434,12 @@ struct dcm_env {
     // its launch -- and k_terminal_flush computes reward + metrics from the snapshots later (every FLUSH_EVERY steps, and before
     // anything reads or writes the summary rows)
     unsigned char* side = nullptr;   // [B][side_pitch]: record image + the env's abandonment rows at the end of the episode
-    uint32_t* pendq = nullptr;       // [0] number of snapshots waiting, [1 .. B] their envs, [1 + B .. 2 B] per-env state (0 / 1 waiting / 2 queued, superseded)
+    uint32_t* pendq = nullptr;       // [B]: 1 = the env's snapshot is waiting for k_terminal_flush
     uint32_t side_pitch = 0;
+    // ... and restarts from a copy of the records dcm_reset produced (reset_state + the first event depend on the instance only)
+    // instead of recomputing them; dropped by anything that changes instances or records behind the kernel's back
+    unsigned char* init = nullptr;   // [B][rec_bytes]
+    bool init_valid = false, init_failed = false;
     int steps_since_flush = 0;
     bool maybe_pending = false, side_failed = false;
     bool captured = false;           // a dcm_step of this handle was captured into a graph: every later step computes its metrics inline

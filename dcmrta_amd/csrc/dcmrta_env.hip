@@ -1963,6 +1963,7 @@ int dcm_destroy(dcm_env* env) {
     if (env->sizes) (void)hipFree(env->sizes);
     if (env->side) (void)hipFree(env->side);
     if (env->pendq) (void)hipFree(env->pendq);
+    if (env->init) (void)hipFree(env->init);
     delete env;
     return DCM_OK;
 }
@@ -2012,25 +2013,23 @@ int dcm_load_instances_ragged(dcm_env* env, const double* depot, const double* t
 namespace dcm {
 int flush_pending(dcm_env* env, void* stream) {
     if (!env->maybe_pending) return DCM_OK;
-    const unsigned grid = (unsigned)(env->p.n_envs < 512 ? env->p.n_envs : 512);
 #define CALL(CA, CT, RS)                                                                                             \
-    hipLaunchKernelGGL((k_terminal_flush<CA, CT, RS>), dim3(grid), dim3(dcm::WAVE),                                    \
+    hipLaunchKernelGGL((k_terminal_flush<CA, CT, RS>), GRID(env),                                    \
                        (Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u + (step_scratch_in_lds<CA, CT>() ? env->L.scratch_bytes() : 0u), \
                        (hipStream_t)stream, DIMS(env), env->kp, (const unsigned char*)env->side, env->side_pitch, env->pendq,       \
-                       (uint32_t)env->p.n_envs, env->summary, (const int32_t*)env->sizes, env->gscratch)
+                       env->summary, (const int32_t*)env->sizes, env->gscratch)
     const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
     if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
     else { CALL(64, 64, true); }
 #undef CALL
     LAUNCH_OK();
-    HIP_TRY(hipMemsetAsync(env->pendq, 0, sizeof(uint32_t), (hipStream_t)stream));     // the count; the kernel cleared the envs' flags
     env->maybe_pending = false;
     env->steps_since_flush = 0;
     return DCM_OK;
 }
 int drop_pending(dcm_env* env, void* stream) {
     if (!env->maybe_pending) return DCM_OK;
-    HIP_TRY(hipMemsetAsync(env->pendq, 0, (size_t)(1 + 2 * (size_t)env->p.n_envs) * sizeof(uint32_t), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(env->pendq, 0, (size_t)env->p.n_envs * sizeof(uint32_t), (hipStream_t)stream));
     env->maybe_pending = false;
     env->steps_since_flush = 0;
     return DCM_OK;
@@ -2053,6 +2052,22 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     if (env->log.len)
         HIP_TRY(hipMemsetAsync(env->log.len, 0, (size_t)env->p.n_envs * env->A * sizeof(int32_t), (hipStream_t)stream));
     env->reset_done = true;
+    // the restart image of the register-resident lockstep kernel (dcm_env::init): what this reset produced
+    env->init_valid = false;
+    if ((env->p.flags & DCM_PARAM_AUTO_RESET) && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && !env->init_failed) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+        const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();
+        if (!env->init && !capturing && hipMalloc((void**)&env->init, sb) != hipSuccess) {
+            (void)hipGetLastError();                                         // out of memory: the kernel restarts the long way
+            env->init = nullptr;
+            env->init_failed = true;
+        }
+        if (env->init && !capturing) {
+            HIP_TRY(hipMemcpyAsync(env->init, env->state, sb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            env->init_valid = true;
+        }
+    }
     return DCM_OK;
 }
 
@@ -2116,7 +2131,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
             } else if (!env->captured) {
                 if (!env->side && !env->side_failed) {
                     const uint32_t pitch = dcm::align16(env->L.rec_bytes() + (uint32_t)env->L.A * dcm::AB_CAP * (uint32_t)sizeof(uint16_t));
-                    const size_t qn = 1 + 2 * (size_t)env->p.n_envs;
+                    const size_t qn = (size_t)env->p.n_envs;
                     if (hipMalloc((void**)&env->side, (size_t)env->p.n_envs * pitch) != hipSuccess ||
                         hipMalloc((void**)&env->pendq, qn * sizeof(uint32_t)) != hipSuccess ||
                         hipMemset(env->pendq, 0, qn * sizeof(uint32_t)) != hipSuccess) {
@@ -2135,7 +2150,7 @@ int dcm_step(dcm_env* env, const int32_t* actions, const int32_t* leader_in, con
                        (hipStream_t)stream, DIMS(env), env->kp,                                                            \
                        env->state, actions, agents_out, tasks_out, mask_out, leader_out, active_out, env->summary, env->ablog,  \
                        env->p.flags, (const int32_t*)env->sizes, env->gscratch, env->p.auto_reset_episodes, env->retlog, (int)env->retcap, \
-                       env->side, env->side_pitch, pendq)
+                       env->side, env->side_pitch, pendq, (pendq && env->init_valid) ? (const unsigned char*)env->init : nullptr)
         const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
         if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
         else { CALL(64, 64, true); }
@@ -2324,6 +2339,7 @@ int dcm_restore_state(dcm_env* env, const void* src, void* stream) {
                            side_bytes(env->p.n_envs, env->A, env->T), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     env->loaded = true;
     env->reset_done = true;
+    env->init_valid = false;          // (the restored records may belong to other instances)
     return DCM_OK;
 }
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
                                                    float* agents_out, float* tasks_out, uint8_t* mask_out, int32_t* leader_out,
                                                    uint8_t* active_out, double* summary, uint16_t* ablog, uint32_t mode,
                                                    const int32_t* sizes, unsigned char* gscr, uint32_t max_episodes, double* retlog,
-                                                   int retcap, unsigned char* side, uint32_t side_pitch, uint32_t* pendq) {
+                                                   int retcap, unsigned char* side, uint32_t side_pitch, uint32_t* pendq, const unsigned char* init) {
     const int e = env_of_workgroup(), lane = threadIdx.x;
     int eA, eT;
     env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
@@ -183,7 +183,17 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
             // in a region of its own that the common path never rejoins.  Its out-of-line terminal metrics clobber 96 scalar and 68
             // vector registers; with one shared tail behind the call the common path's values lived across it and the kernel sat at
             // its 128-VGPR limit with 40 B of spills, some of them on the common path.  Two tails: 105 VGPRs, no spills of its own.
+            // The restart's image (dcm_env::init: the record dcm_reset left, i.e. reset_state + the first event of this instance) is
+            // requested now and lands in LDS behind the snapshot: its round trip hides behind the end-of-episode code, and the wave
+            // skips reset_state + the first advance() (3700 of its 21 400 clocks at 4096 envs)
+            constexpr uint32_t IN16 = Lay{CA, CT}.mut_bytes() / 16, ICH = (IN16 + WAVE - 1) / WAVE;
+            u32x4 iv[ICH];
             if (plain) {
+                if (init) {
+                    const u32x4* q = (const u32x4*)(init + (size_t)e * L.rec_bytes());
+#pragma unroll
+                    for (uint32_t c = 0; c < ICH; c++) { const uint32_t i = c * WAVE + lane; iv[c] = __builtin_nontemporal_load(q + (i < IN16 ? i : IN16 - 1)); }
+                }
                 f.flush(r);
                 // Deferred terminal metrics (pendq != nullptr, see dcm_env::side): if this event ends the episode and the env restarts
                 // right away, the wave only parks the final record; calculate_waiting_time -- 6-7 us of this wave's 13-15, and this
@@ -210,37 +220,59 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
             }
             h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
             h.empty_passes = uni(h.empty_passes); h.d = uni(h.d);
-            if (h.flags & SimT::FLAG_DEFERRED) {
-                // park the record (the LDS image is current: an episode only ever ends in the general code), the final time and the
-                // env's abandonment rows (its own earlier stores: agent-scope loads, past the CU's vector L1), then announce it
+            // park the record (the LDS image is current: an episode only ever ends in the general code), the final time and the env's
+            // abandonment rows (its own earlier stores: agent-scope loads, past the CU's vector L1), then announce it.  The rows are
+            // requested here and stored behind the restart, which hides their round trip (1 us of this wave, the launch's slowest)
+            const bool deferred = (h.flags & SimT::FLAG_DEFERRED) != 0u;
+            unsigned char* const sp = side + (size_t)e * side_pitch;
+            constexpr int ABN = 64 * (AB_CAP / 4) / WAVE;            // rows of at most 64 agents, as 64-bit words per lane
+            unsigned long long ab[ABN] = {};
+            const int nab = S.A() * (AB_CAP / 4);
+            if (deferred) {
                 h.flags &= ~SimT::FLAG_DEFERRED;
-                unsigned char* sp = side + (size_t)e * side_pitch;
+                const unsigned long long* src = (const unsigned long long*)S.ablog();
+#pragma unroll
+                for (int k = 0; k < ABN; k++)
+                    if (lane + k * WAVE < nab) ab[k] = __hip_atomic_load(src + lane + k * WAVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 WSYNC();
                 copy16(sp, smem, L.rec_bytes(), lane);
-                const unsigned long long* src = (const unsigned long long*)S.ablog();
-                unsigned long long* dst = (unsigned long long*)(sp + L.rec_bytes());
-                for (int i = lane; i < S.A() * (AB_CAP / 4); i += WAVE) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) {
                     ((Hdr*)sp)->now = h.now;          // (after lane 0's own copy of the header piece: same lane, same address, in order)
-                    uint32_t* const st = &pendq[1u + gridDim.x + (uint32_t)e];      // 0 not queued, 1 snapshot waiting, 2 queued but stale
-                    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) pendq[1u + atomicAdd(&pendq[0], 1u)] = (uint32_t)e;
-                    *st = 1u;
+                    pendq[e] = 1u;
                 }
             } else if (pendq && (h.flags & DCM_FLAG_DONE) && lane == 0) {
                 // the episode ended with its metrics computed here (masked action, overflowed log, last episode of the handle's budget):
                 // a snapshot of an earlier episode must not overwrite the row later
-                uint32_t* const st = &pendq[1u + gridDim.x + (uint32_t)e];
-                if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) *st = 2u;
+                pendq[e] = 0u;
             }
             // DCM_PARAM_AUTO_RESET: the episode has just ended -> start the next one from the loaded instance (see k_step); an episode
             // only ever ends in the general code, so the LDS image is current here
             if ((mode & DCM_PARAM_AUTO_RESET) && (h.flags & DCM_FLAG_DONE) && !(h.flags & ERR) &&
                 (max_episodes == 0 || uni(((const Hdr*)smem)->episodes) < max_episodes)) {
-                S.reset_state(h, lane);
-                if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
-                S.advance(h, P, lane, row PH_PASS, false);
-                h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
-                h.empty_passes = uni(h.empty_passes);
+                if (deferred && init) {
+                    // (a deferred end is a plain one: the image was requested.  LDS operations of a wave execute in order, so the
+                    //  snapshot's reads of the old image are done)
+                    const uint32_t ep = uni(((const Hdr*)smem)->episodes);
+                    u32x4* d = (u32x4*)smem;
+#pragma unroll
+                    for (uint32_t c = 0; c < ICH; c++) { const uint32_t i = c * WAVE + lane; d[i < IN16 ? i : IN16 - 1] = iv[c]; }
+                    WSYNC();
+                    const HdrRegs hi = load_hdr(smem);                  // time 0, first group of the first event; seed unchanged since dcm_reset
+                    h.now = hi.now; h.flags = hi.flags; h.cur_group = hi.cur_group; h.n_groups = hi.n_groups; h.empty_passes = hi.empty_passes;
+                    if (lane == 0) { ((Hdr*)smem)->episodes = ep; *S.dirty() = SimT::DIRTY_ALL; }
+                } else {
+                    S.reset_state(h, lane);
+                    if (lane == 0) *S.dirty() = SimT::DIRTY_ALL;
+                    S.advance(h, P, lane, row PH_PASS, false);
+                    h.now = uni(h.now); h.flags = uni(h.flags); h.cur_group = uni(h.cur_group); h.n_groups = uni(h.n_groups);
+                    h.empty_passes = uni(h.empty_passes);
+                }
+            }
+            if (deferred) {
+                unsigned long long* dst = (unsigned long long*)(sp + L.rec_bytes());
+#pragma unroll
+                for (int k = 0; k < ABN; k++)
+                    if (lane + k * WAVE < nab) dst[lane + k * WAVE] = ab[k];
             }
             finish(false);
             return;
@@ -254,35 +286,28 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
 
 
 // Reward + perf metrics (env/task_env.py:344-364,420-425, worker.py:103-108) of the episodes whose final records k_step_fast parked
-// (dcm_env::side): workgroup i takes snapshots i, i + gridDim.x, ...; the host clears the count behind the launch (same stream).
+// (dcm_env::side): one workgroup per env, those without a waiting snapshot leave at once.
 template <int CA, int CT, bool RS>
 __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_terminal_flush(int A, int T, int PA, int PT, KP P, const unsigned char* side, uint32_t side_pitch,
-                                                        uint32_t* pendq, uint32_t B, double* summary, const int32_t* sizes, unsigned char* gscr) {
-    const int lane = threadIdx.x;
+                                                        uint32_t* pendq, double* summary, const int32_t* sizes, unsigned char* gscr) {
+    const int e = env_of_workgroup(), lane = threadIdx.x;
+    if (uni(pendq[e]) == 0u) return;
+    int eA, eT;
+    env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
     using SimT = Sim<CA, CT, RS, false>;
-    const uint32_t n = uni(pendq[0]);
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const int e = (int)uni(pendq[1u + i]);
-        if (uni(pendq[1u + B + (uint32_t)e]) != 1u) {            // a later episode's row was computed by the step kernel itself
-            if (lane == 0) pendq[1u + B + (uint32_t)e] = 0u;
-            continue;
-        }
-        int eA, eT;
-        env_dims<CA, CT, RS>(sizes, e, A, T, eA, eT);
-        SimT S{eA, eT, PA, PT, smem, nullptr};
-        const Lay L = S.L();
-        S.scr = step_scratch_in_lds<CA, CT>() ? smem + SimT::lds_image_bytes(L) + 512u : gscr + (size_t)e * L.scratch_bytes();
-        const unsigned char* sp = side + (size_t)e * side_pitch;
-        WSYNC();                                                 // (the previous snapshot's LDS reads are done)
-        copy16_in(smem, sp, L.rec_bytes(), lane);
-        if (lane == 0) {                                         // the image's pointers: this snapshot's abandonment rows, nothing else
-            *(const uint16_t**)(smem + S.aux_off()) = (const uint16_t*)(sp + L.rec_bytes());
-            *(uint8_t**)(smem + S.aux_off() + 16) = nullptr;     // (a log that overflowed into the count table is never deferred)
-            *(double**)(smem + S.aux_off() + 32) = nullptr;
-        }
-        WSYNC();
-        const double now = uni(((const Hdr*)smem)->now);
-        (void)SimT::terminal_metrics(S, now, P.mwt, lane, summary + (size_t)e * 8);
-        if (lane == 0) pendq[1u + B + (uint32_t)e] = 0u;
+    SimT S{eA, eT, PA, PT, smem, nullptr};
+    const Lay L = S.L();
+    S.scr = step_scratch_in_lds<CA, CT>() ? smem + SimT::lds_image_bytes(L) + 512u : gscr + (size_t)e * L.scratch_bytes();
+    const unsigned char* sp = side + (size_t)e * side_pitch;
+    typename SimT::XY xy;
+    S.template load_record<false>(sp, lane, xy);                 // (every load in flight before the first LDS write)
+    if (lane == 0) {                                             // the image's pointers: this snapshot's abandonment rows, nothing else
+        *(const uint16_t**)(smem + S.aux_off()) = (const uint16_t*)(sp + L.rec_bytes());
+        *(uint8_t**)(smem + S.aux_off() + 16) = nullptr;         // (a log that overflowed into the count table is never deferred)
+        *(double**)(smem + S.aux_off() + 32) = nullptr;
     }
+    WSYNC();
+    const double now = uni(((const Hdr*)smem)->now);
+    (void)SimT::terminal_metrics(S, now, P.mwt, lane, summary + (size_t)e * 8);
+    if (lane == 0) pendq[e] = 0u;
 }

@@ -138,3 +138,45 @@ def test_capture_is_refused_while_summaries_wait_and_inline_under_capture(gpu_de
     assert torch.equal(env.episodes(), ref.episodes())
     sm, rm = env.summary(), ref.summary()
     assert torch.equal(sm.view(torch.int64), rm.view(torch.int64))
+
+
+def test_restart_image_follows_reloads_and_restores(gpu_device, oracle_lib):
+    """The register-resident step restarts an env from a copy of the records dcm_reset produced.  The copy must follow the
+    handle: new instances + reset refresh it, dcm_restore_state (records of possibly other instances) drops it -- the kernel then
+    recomputes the restart -- and either way every episode is the oracle's."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 40, 7, 9
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True)
+
+    def play(inst, seeds, steps, restore_at=None, other=None):
+        ring = env.enable_return_log(64)
+        env.load_instances(**inst)
+        obs = env.reset(seeds)
+        dcount = np.zeros(B, np.int64)
+        for s in range(steps):
+            if s == restore_at:                       # records of ANOTHER instance set, mid-episode, then back: the image is dropped
+                keep = env.clone_state()
+                env.restore_state(other)
+                env.restore_state(keep)
+            mk = obs.mask.cpu().numpy().astype(np.uint8)
+            act = np.array([H.host_random_action(mk[b], int(seeds[b]), int(dcount[b])) for b in range(B)], np.int32)
+            obs = env.step(act)
+            dcount += 1
+        eps = env.episodes().cpu().numpy()
+        sm = env.summary().cpu().numpy()
+        rl = ring.cpu().numpy()
+        assert eps.min() >= 2 and eps.max() <= 64
+        for b in range(B):
+            ref = _oracle_episodes(oracle_lib, inst, seeds, A, T, b, int(eps[b]))
+            for k, r in enumerate(ref):
+                assert rl[b, k] == r["reward"], (b, k)
+            for i in range(6):
+                assert sm[b, 2 + i] == ref[-1]["metrics"][i], (b, i)
+
+    inst1, inst2 = generate_batch(B, A, T, base_seed=7500), generate_batch(B, A, T, base_seed=7600)
+    play(inst1, env_seeds(37, 0, B), 120)
+    other = env.clone_state()                         # mid-episode records of the first instance set
+    play(inst2, env_seeds(41, 0, B), 120)             # same handle, new instances: the image is refreshed by the reset
+    play(inst2, env_seeds(43, 0, B), 150, restore_at=40, other=other)

@@ -34,6 +34,6 @@ torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 med = ms[len(ms) // 2]
 W = algorithmic_bytes_per_step(A, T)
-print(f"B={B} {A}A/{T}T{' steady state' if STEADY else ''} k_step min {ms[0]*1e3:.1f} p25 {ms[len(ms)//4]*1e3:.1f} max {ms[-1]*1e3:.1f} us")
+print(f"B={B} {A}A/{T}T{' steady state' if STEADY else ''} k_step min {ms[0]*1e3:.1f} p25 {ms[len(ms)//4]*1e3:.1f} max {ms[-1]*1e3:.1f} mean {sum(ms)/len(ms)*1e3:.1f} us")
 print(f"B={B} {A}A/{T}T k_step median {med*1e3:.1f} us  -> {B/med*1e3:.3e} steps/s, {B*W/med/1e6:.0f} GB/s algorithmic "
       f"({B*W/med/1e6/8000*100:.1f} % of 8 TB/s)")
