@@ -13,6 +13,14 @@ python tools/collect_profile.py ${R}_70A130T ${R}_70A130T k_rollout_fast_g > /de
 python tools/collect_lockstep.py ${R}_lockstep 4096 20 50 > /dev/null
 python tools/collect_lockstep.py ${R}_lockstep 65536 20 50 > /dev/null
 python tools/collect_lockstep.py ${R}_lockstep 16384 50 200 > /dev/null
+# the steady-state collection loop: the probe's log + the kernel stats of the same loop (k_step_fast, k_terminal_flush)
+[ -s gpurun_out/${R}_lockstep_steady.log ] && grep -v "amdgpu.ids" gpurun_out/${R}_lockstep_steady.log > profiles/${R}_lockstep_steady.log
+if [ -d gpurun_out/prof_${R}_steady ]; then
+  mkdir -p profiles/${R}_lockstep_steady
+  cp gpurun_out/prof_${R}_steady/command.txt profiles/${R}_lockstep_steady/
+  f=$(find gpurun_out/prof_${R}_steady -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && (head -1 $f; grep -E "k_step|k_terminal" $f) > profiles/${R}_lockstep_steady/kernel_stats.csv
+fi
 for f in bench bench_config4 bench_config5 bench_config5_generalised bench_config5_static; do
   [ -s gpurun_out/${R}_$f.json ] && grep '^{' gpurun_out/${R}_$f.json | tail -1 > profiles/${R}_$f.json
 done

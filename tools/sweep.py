@@ -26,6 +26,7 @@ bad, checked, t0 = 0, 0, time.time()
 wait_order = 0
 is_cnt = 0
 masked_cnt = 0
+auto_cnt = 0
 for it in range(n_shapes):
     A = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32, 33, 50, 63, 64, 65, 100, 128]))
     T = int(rng.choice([1, 2, 7, 20, 37, 50, 63, 64, 65, 100, 128, 129, 200, 300]))
@@ -100,6 +101,39 @@ for it in range(n_shapes):
                 bad += 1
                 print("MISMATCH", mode, A, T, mwt, base, b, str(ex)[:200], flush=True)
             checked += 1
+        env.close()
+    # a collection loop: DCM_PARAM_AUTO_RESET lockstep with a device-side first-valid policy and no host read until the end (the
+    # register-resident step parks final records and restarts from the reset image; k_terminal_flush computes the summaries):
+    # every episode's return (return log) and the last episode's metrics against the oracle's consecutive episodes
+    if it % 3 == 1 and A <= 64 and T <= 64:
+        nB, n_steps, cap = min(B, 24), 360, 512
+        sub = {k: v[:nB] for k, v in inst.items()}
+        env = BatchedTaskEnv(nB, A, T, max_waiting_time=mwt, max_time=max_time, auto_reset=True).load_instances(**sub)
+        ring = env.enable_return_log(cap)
+        obs = env.reset(seeds[:nB])
+        for _ in range(n_steps):
+            obs = env.step(torch.argmax((~obs.mask).to(torch.int32), dim=1).to(torch.int32))
+        eps = env.episodes().cpu().numpy()
+        sm = env.summary().cpu().numpy()
+        rl = ring.cpu().numpy()
+        dec = env.status()["decisions"].cpu().numpy()
+        for b in range(nB):
+            a, t = int(nA[b]), int(nT[b])
+            o = oracle.OracleEnv(a, t, max_waiting_time=mwt, max_time=max_time).load(inst["depot"][b], inst["task_xy"][b, :t], inst["req"][b, :t], inst["dur"][b, :t])
+            d0, ok, last = 0, int(eps[b]) <= cap, None
+            for k in range(min(int(eps[b]), cap)):
+                last = o.rollout(int(seeds[b]), d0, oracle.POLICY_FIRST, cap_steps=100000, record=False)
+                o.clear_decisions()
+                d0 += last["n_steps"]
+                ok = ok and rl[b, k] == last["reward"]
+            if last is not None:
+                ok = ok and sm[b, 0] == last["reward"] and all(sm[b, 2 + i] == last["metrics"][i] or (np.isnan(sm[b, 2 + i]) and np.isnan(last["metrics"][i])) for i in range(6))
+            ok = ok and d0 <= n_steps and dec[b] == n_steps
+            checked += max(int(eps[b]), 1)
+            auto_cnt += int(eps[b])
+            if not ok:
+                bad += 1
+                print("MISMATCH auto-reset lockstep", A, T, mwt, max_time, base, b, "ragged", ragged, int(eps[b]), flush=True)
         env.close()
     # individual selection (Worker.run_test_IS, worker.py:159-198): the device offers the lowest pending id and moves it alone;
     # the reference loop is restated on the oracle's step-wise surface with the same keyed valid-action choice
@@ -181,4 +215,4 @@ for it in range(n_shapes):
                     bad += 1
                     print("MISMATCH mask-ignoring policy", A, T, mwt, base, b, flush=True)
         env.close()
-print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {is_cnt} in individual-selection mode, {masked_cnt} under a mask-ignoring policy, {time.time() - t0:.0f} s")
+print(f"sweep: {n_shapes} shapes, {checked} env-episodes checked, {bad} mismatches, {wait_order} with the wait-order flag, {is_cnt} in individual-selection mode, {masked_cnt} under a mask-ignoring policy, {auto_cnt} episodes of auto-resetting lockstep loops, {time.time() - t0:.0f} s")
