@@ -17,6 +17,7 @@ bash tools/profile_lockstep.sh 65536 20 50 100
 bash tools/profile_lockstep.sh 16384 50 200 100
 # the lockstep API in the steady state of a collection loop (auto-reset: deferred terminal metrics, restart image) + the kernel stats
 # of the same loop at the BASELINE batch (k_step_fast and k_terminal_flush, one launch in 32)
+python tools/lockstep_probe.py 4096 20 50 300 > /dev/null 2>&1          # (the box's first GPU work: clocks still ramping)
 for B in 1024 4096 65536; do python tools/lockstep_probe.py $B 20 50 350 steady; python tools/lockstep_probe.py $B 20 50 100; done > gpurun_out/${R}_lockstep_steady.log 2>&1
 ( export TMPDIR=/tmp; O=$PWD/gpurun_out/prof_${R}_steady; rm -rf $O; mkdir -p $O; P=$PWD/tools/lockstep_probe.py; echo "python3 $P 4096 20 50 350 steady" > $O/command.txt; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $P 4096 20 50 350 steady > $O/stats.log 2>&1 )
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
