@@ -2054,7 +2054,8 @@ int dcm_reset(dcm_env* env, const uint64_t* seeds, void* stream) {
     env->reset_done = true;
     // the restart image of the register-resident lockstep kernel (dcm_env::init): what this reset produced
     env->init_valid = false;
-    if ((env->p.flags & DCM_PARAM_AUTO_RESET) && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && !env->init_failed) {
+    // (max_time <= 0: the first event already ends the episode -- summary row, episode count, return log -- which a copied image cannot redo)
+    if ((env->p.flags & DCM_PARAM_AUTO_RESET) && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && !env->init_failed && env->kp.max_time > 0.0) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
         const size_t sb = (size_t)env->p.n_envs * env->L.rec_bytes();

@@ -180,3 +180,19 @@ def test_restart_image_follows_reloads_and_restores(gpu_device, oracle_lib):
     other = env.clone_state()                         # mid-episode records of the first instance set
     play(inst2, env_seeds(41, 0, B), 120)             # same handle, new instances: the image is refreshed by the reset
     play(inst2, env_seeds(43, 0, B), 150, restore_at=40, other=other)
+
+
+def test_zero_max_time_handle_keeps_the_computed_restart(gpu_device):
+    """max_time <= 0: the loop test fails before the first decision (worker.py:45), so a restart ends its episode at once -- which only
+    the computed restart can account for (summary row, episode count); such a handle gets no restart image and stays consistent."""
+    from dcmrta_amd.batched_env import BatchedTaskEnv
+    from dcmrta_amd.choice import env_seeds
+    from dcmrta_amd.instances import generate_batch
+    B, A, T = 8, 5, 7
+    env = BatchedTaskEnv(B, A, T, device=gpu_device, auto_reset=True, max_time=0.0).load_instances(**generate_batch(B, A, T, base_seed=7700))
+    obs = env.reset(env_seeds(47, 0, B))
+    for _ in range(3):
+        obs = env.step(torch.zeros(B, dtype=torch.int32, device=gpu_device))
+    assert not bool(obs.active.any())
+    assert torch.equal(env.episodes().cpu(), torch.ones(B, dtype=torch.int32))
+    assert torch.equal(env.summary()[:, 0].cpu(), torch.zeros(B, dtype=torch.float64))      # reward = -now = -0.0 (== 0.0)
