@@ -343,6 +343,14 @@ __device__ __forceinline__ void copy16(unsigned char* dst, const unsigned char* 
 }
 // record HBM -> LDS: streamed once, keep it out of the way of the observation stores in L2
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// LDS -> HBM with non-temporal stores: the lockstep kernels' write-back and observation rows at batches far larger than the L2s
+// (nothing re-reads the lines before they would be evicted anyway; measured -5 % per 65 536-env launch, no change at 4096, where
+// the next step's record loads still hit L2 and the plain stores stay)
+__device__ __forceinline__ void copy16_nt(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
+    const u32x4* s = (const u32x4*)src;
+    u32x4* d = (u32x4*)dst;
+    for (uint32_t i = lane; i < bytes / 16; i += WAVE) __builtin_nontemporal_store(s[i], d + i);
+}
 __device__ __forceinline__ void copy16_in(unsigned char* dst, const unsigned char* src, uint32_t bytes, int lane) {
     const u32x4* s = (const u32x4*)src;
     u32x4* d = (u32x4*)dst;

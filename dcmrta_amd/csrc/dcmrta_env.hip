@@ -1492,9 +1492,10 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
         // word of one task and -- when a task became feasible -- the two time arrays: ~2.4 of the 4.6 KB at 20A/50T).
         // Ranges are widened to 16-byte boundaries; the bytes around them are unchanged copies of what HBM already holds.
         const uint32_t dm = uni(*S.dirty());
+        const bool big = gridDim.x >= 8192u;           // far more state than the L2s hold: stream the stores (copy16_nt)
         auto put = [&](uint32_t lo, uint32_t hi) {     // [lo, hi) of the record
             lo &= ~15u; hi = (hi + 15u) & ~15u;
-            copy16(rec + lo, smem + lo, hi - lo, lane);
+            if (big) copy16_nt(rec + lo, smem + lo, hi - lo, lane); else copy16(rec + lo, smem + lo, hi - lo, lane);
         };
         const uint32_t Tn = (uint32_t)S.PT();
         put(0, L.tb());                                                               // header + agent arrays
@@ -1553,9 +1554,9 @@ __global__ __launch_bounds__(WAVE) void k_step(int A, int T, int PA, int PT, KP 
                 uint8_t* smk = (uint8_t*)(stk + 5 * (S.T() + 1));
                 S.observe(h, lane, leader, ag ? sag : nullptr, tk ? stk : nullptr, mk ? smk : nullptr, xy);
                 WSYNC();
-                if (ag) for (int i = lane; i < 6 * S.A(); i += WAVE) ag[i] = sag[i];
-                if (tk) for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) tk[i] = stk[i];
-                if (mk) for (int i = lane; i <= S.T(); i += WAVE) mk[i] = smk[i];
+                if (ag) for (int i = lane; i < 6 * S.A(); i += WAVE) __builtin_nontemporal_store(sag[i], ag + i);
+                if (tk) for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) __builtin_nontemporal_store(stk[i], tk + i);
+                if (mk) for (int i = lane; i <= S.T(); i += WAVE) __builtin_nontemporal_store(smk[i], mk + i);
             } else {
                 S.observe(h, lane, leader, ag, tk, mk, xy);
             }

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
         // write back what the step can have changed (see k_step)
         const uint32_t sd = uni(*S.dirty());
         const uint32_t dm = sd | f.dirty;
+        const bool big = gridDim.x >= 8192u;           // (see copy16_nt)
         auto put = [&](uint32_t lo, uint32_t hi) {
             lo &= ~15u; hi = (hi + 15u) & ~15u;
-            copy16(rec + lo, smem + lo, hi - lo, lane);
+            if (big) copy16_nt(rec + lo, smem + lo, hi - lo, lane); else copy16(rec + lo, smem + lo, hi - lo, lane);
         };
         const uint32_t Tn = (uint32_t)S.PT();
         // When only the register-resident step has touched the record (no general code: sd == 0) and it removed nobody, what it
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(WAVE, DCM_STEP_WAVES) void k_step_fast(int A, int T
         else S.observe(h, lane, leader, oag, otk, omk, xy);
         if (staged) {
             WSYNC();
-            for (int i = lane; i < 6 * S.A(); i += WAVE) ag[i] = sag[i];
-            for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) tk[i] = stk[i];
-            for (int i = lane; i <= S.T(); i += WAVE) mk[i] = smk[i];
+            for (int i = lane; i < 6 * S.A(); i += WAVE) __builtin_nontemporal_store(sag[i], ag + i);
+            for (int i = lane; i < 5 * (S.T() + 1); i += WAVE) __builtin_nontemporal_store(stk[i], tk + i);
+            for (int i = lane; i <= S.T(); i += WAVE) __builtin_nontemporal_store(smk[i], mk + i);
         }
     } else {
         S.write_inactive_obs(lane, ag, tk, mk);
