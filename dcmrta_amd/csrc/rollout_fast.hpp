@@ -317,8 +317,9 @@ struct Fast {
         return nth(gm, below((uint32_t)(k1 >> 32), glen));
     }
     // k2p: the decision's second key mix64(k1 + GAMMA) (the first two follower draws) if the caller has it, else nullptr
+    // nvp: receives the number of unmasked tasks the decision saw (the launch's wave-priority estimate of the work left)
     __device__ __forceinline__ int decide(R& r, HdrRegs& h, const KP& P, int lane, uint64_t k1, float* agrow, float* tkrow, uint8_t* mkp,
-                                          const uint64_t* k2p = nullptr) const {
+                                          const uint64_t* k2p = nullptr, int* nvp = nullptr) const {
         uint64_t gm;
         // (no early return: an exit from the middle of a decision would keep the whole register set of the agent / task state alive
         //  in a second copy -- 15 v_mov per decision at the loop latch.  An empty group is unreachable; if it ever happened the env
@@ -330,6 +331,7 @@ struct Fast {
         FPH(1);
         // uniform-random valid action (protocol slot 1)
         const int nv = __popcll(bm);
+        if (nvp) *nvp = nv;
         const int action = nv ? nth(bm, below((uint32_t)k1, nv)) + 1 : 0;
         FPH(2);
         return apply(r, h, P, lane, k1, gm, leader, action, k2p);
@@ -542,6 +544,26 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     PH_DECL;
     int ep = 0;
     bool need_adv = false;       // the general event code has to run on the (flushed) LDS image before the next decision
+    // Wave priority = longest remaining work first (s_setprio).  A launch that fills the machine by itself ends with its slowest env
+    // (430 of a mean 360 decisions at 20A/50T x 3 episodes) while the SIMDs it shares with envs that finished early idle; the waves
+    // with the most tasks still to serve -- episodes to come x T + the unmasked tasks of the last decision, in sixths of the launch's
+    // total: 4/6, 2/6, 1/6 -- win the instruction arbiter, so the four waves of a SIMD finish together: one 4096-env launch 1.237 ->
+    // 1.091 ms (3 episodes), 0.447 -> 0.426 (1 episode), 8192 envs 2.23 -> 2.05.  Re-evaluated at episode ends and at the key refill
+    // (every 64 decisions): nothing per decision.  Not for sub-batches that share the SIMDs with other launches (grid < 4096: several
+    // streams, whose tails already overlap the others' bodies; priorities across launches measured -1 ... -5 % there, also with a
+    // common deadline clock), nor in the multi-chunk kernels (their launches run in several rounds of workgroups: +0.5 / -3 %).
+    const bool use_prio = gridDim.x >= 4096u;
+    int nv_last = S.T(), prio_lv = 3;
+    auto set_prio = [&](int ep_now) {
+        const int rem6 = 6 * ((episodes - ep_now - 1) * S.T() + nv_last), tot = episodes * S.T();
+        const int lv = rem6 >= 4 * tot ? 3 : (rem6 >= 2 * tot ? 2 : (rem6 >= tot ? 1 : 0));
+        if (lv != prio_lv) {
+            prio_lv = lv;
+            if (lv == 3) __builtin_amdgcn_s_setprio(3); else if (lv == 2) __builtin_amdgcn_s_setprio(2);
+            else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    if (use_prio) __builtin_amdgcn_s_setprio(3);
     for (;;) {
         if (!need_adv) {         // head of an episode slot (the `for ep` of k_rollout_random)
             if (ep >= episodes) break;
@@ -568,10 +590,10 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
                 FPHK(f, 12);
                 CNT(0);
                 const uint64_t k1 = F::rl(kv, ki), k2 = F::rl(kv2, ki);
-                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, &k2);
+                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, &k2, &nv_last);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
-                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; }
+                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; if (use_prio) set_prio(ep); }
                 left--;
                 if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
                     CNT(8);
@@ -586,6 +608,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
         }
         if (left == 0) break;
         ep++;
+        if (use_prio && ep < episodes) { nv_last = S.T(); set_prio(ep); }
     }
     PH_FLUSH(lane);
     FPHK(f, 13);
