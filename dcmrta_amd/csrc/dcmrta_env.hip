@@ -1938,6 +1938,8 @@ int dcm_create(const dcm_params* params, dcm_env** out) {
 #define SET_FAST(CA, CT, RS)                                                                                              \
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
     (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);  \
+    (void)hipFuncSetAttribute((const void*)k_rollout_fast<CA, CT, RS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
     (void)hipFuncSetAttribute((const void*)k_step_fast<CA, CT, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
     FOR_EACH_FAST(SET_FAST);
 #undef SET_FAST
@@ -2189,12 +2191,15 @@ int dcm_rollout_random(dcm_env* env, int32_t episodes, int64_t max_decisions, co
     // none: the register-resident kernel.  Same contract, same results (tests/test_gpu_rollout.py runs both).
     const bool all_obs = agents_out && tasks_out && mask_out, no_obs = !agents_out && !tasks_out && !mask_out;
     if (quiet_ok && env->L.C == M && env->L.A <= 64 && env->L.T <= 64 && env->T <= 63 && (all_obs || no_obs)) {
-#define CALLF(CA, CT, RS, OBS)                                                                                        \
-    hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS>), GRID(env),                                                  \
+#define CALLF(CA, CT, RS, OBS, PRIO)                                                                                  \
+    hipLaunchKernelGGL((k_rollout_fast<CA, CT, RS, OBS, PRIO>), GRID(env),                                            \
                        (Sim<CA, CT, RS>::SCR_IN_LDS ? env->L.lds_bytes() : Sim<CA, CT, RS>::lds_image_bytes(env->L)) + 512u, (hipStream_t)stream, DIMS(env), \
                        env->kp, env->state, (int)episodes, agents_out, tasks_out, mask_out, steps_out, env->summary, env->ablog, \
                        (const int32_t*)env->sizes, max_decisions, max_decisions_in, env->gscratch, env->retlog, (int)env->retcap)
-#define CALL(CA, CT, RS) do { if (all_obs) { CALLF(CA, CT, RS, true); } else { CALLF(CA, CT, RS, false); } } while (0)
+        // wave priorities (k_rollout_fast, PRIO) for a launch that fills the machine by itself: 16 workgroups x 256 CUs
+        const bool prio = env->p.n_envs >= 4096;
+#define CALL(CA, CT, RS) do { if (prio) { if (all_obs) { CALLF(CA, CT, RS, true, true); } else { CALLF(CA, CT, RS, false, true); } }   \
+                              else { if (all_obs) { CALLF(CA, CT, RS, true, false); } else { CALLF(CA, CT, RS, false, false); } } } while (0)
         const bool exact_ = !env->sizes && env->A == env->L.A && env->T == env->L.T;
         if (env->L.A == 20 && env->L.T == 50) { if (exact_) { CALL(20, 50, false); } else { CALL(20, 50, true); } }
         else { CALL(64, 64, true); }

@@ -490,7 +490,8 @@ struct Fast {
 };
 
 // Same contract as k_rollout_random (see there); OBS: all three observation buffers given / none of them.
-template <int CA, int CT, bool RS, bool OBS>
+// PRIO: wave priorities, longest remaining work first (see the main loop) -- the host picks it for launches that fill the machine alone
+template <int CA, int CT, bool RS, bool OBS, bool PRIO = false>
 __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, int PT, KP P, unsigned char* state, int episodes,
                                                       float* agents_out, float* tasks_out, uint8_t* mask_out,
                                                       int64_t* steps_out, double* summary, uint16_t* ablog,
@@ -552,7 +553,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
     // (every 64 decisions): nothing per decision.  Not for sub-batches that share the SIMDs with other launches (grid < 4096: several
     // streams, whose tails already overlap the others' bodies; priorities across launches measured -1 ... -5 % there, also with a
     // common deadline clock), nor in the multi-chunk kernels (their launches run in several rounds of workgroups: +0.5 / -3 %).
-    const bool use_prio = gridDim.x >= 4096u;
+    // A template parameter, not a run-time test: the bookkeeping alone (one more live scalar, the refill path) cost the
+    // unprioritised four-stream line 0.45 %.
+    constexpr bool use_prio = PRIO;
     int nv_last = S.T(), prio_lv = 3;
     auto set_prio = [&](int ep_now) {
         const int rem6 = 6 * ((episodes - ep_now - 1) * S.T() + nv_last), tot = episodes * S.T();
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
             else if (lv == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
     };
-    if (use_prio) __builtin_amdgcn_s_setprio(3);
+    if constexpr (use_prio) __builtin_amdgcn_s_setprio(3);
     for (;;) {
         if (!need_adv) {         // head of an episode slot (the `for ep` of k_rollout_random)
             if (ep >= episodes) break;
@@ -590,10 +593,10 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
                 FPHK(f, 12);
                 CNT(0);
                 const uint64_t k1 = F::rl(kv, ki), k2 = F::rl(kv2, ki);
-                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, &k2, &nv_last);
+                const int rlen = f.decide(r, h, P, lane, k1, agrow, tkrow, mkp, &k2, use_prio ? &nv_last : nullptr);
                 if (h.flags & DCM_FLAG_DONE) break;
                 gd += GAMMA;
-                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; if (use_prio) set_prio(ep); }
+                if (++ki == WAVE) { kv = mix64(gd + GAMMA * (uint64_t)lane); kv2 = mix64(kv + GAMMA); ki = 0; if constexpr (use_prio) set_prio(ep); }
                 left--;
                 if (rlen == 0) {                                                  // worker.py:53 else same group, next leader
                     CNT(8);
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_rollout_fast(int A, int T, int PA, 
         }
         if (left == 0) break;
         ep++;
-        if (use_prio && ep < episodes) { nv_last = S.T(); set_prio(ep); }
+        if constexpr (use_prio) { if (ep < episodes) { nv_last = S.T(); set_prio(ep); } }
     }
     PH_FLUSH(lane);
     FPHK(f, 13);

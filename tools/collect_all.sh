@@ -2,8 +2,8 @@
 # condense the gpurun_out/prof_* directories of the round's evidence run (tools/evidence_run.sh) into profiles/ (run in the build container)
 set -e
 R=${1:-r05}
-python tools/collect_profile.py ${R}_s4 ${R}_streams4 k_rollout_fast > /dev/null
-python tools/collect_profile.py ${R}_s1 ${R}_streams1 k_rollout_fast > /dev/null        # last: the source of config 2's counters.json entry
+python tools/collect_profile.py ${R}_s1 ${R}_streams1 k_rollout_fast > /dev/null        # one 4096-env launch per pass: the PRIO instantiation (wave priorities)
+python tools/collect_profile.py ${R}_s4 ${R}_streams4 k_rollout_fast > /dev/null        # last = the source of config 2's counters.json entry: the product line's four 1024-env launches
 python tools/collect_profile.py ${R}_c4 ${R}_config4 k_rollout_fast_mc > /dev/null
 python tools/collect_profile.py ${R}_c5 ${R}_config5 k_replay_fast > /dev/null
 python tools/collect_profile.py ${R}_c5gen ${R}_config5_generalised k_replay > /dev/null
