@@ -243,7 +243,8 @@ def test_persistent_kernel_keeps_four_waves_per_simd(tmp_path):
             if "ILi2ELi3ELb1E" in name or "ILi1ELi2ELb1E" in name:       # ... without spills for the 70A/130T- and 30A/100T-class batches
                 assert spills[name] == 0, (name, spills[name])
             seen += 1
-    assert seen == 7 + 12, sorted(usage)
+    # 3 general + 6 register-resident (three layouts, with and without the wave-priority bookkeeping) + config 4 + 12 mid-size
+    assert seen == 10 + 12, sorted(usage)
 
 
 def test_synthetic_route_arrays_match_the_list_form():
