@@ -218,6 +218,15 @@ def lockstep_kernel_probe(A, T, dev, B=65536, n=100, warm=5):
         # (with deferred terminal metrics one dcm_step in 32 also launches k_terminal_flush: in the mean, not in the median)
         out["steady_state_mean_us"] = sum(us) / len(us)
         out["steady_state_envs"] = Bs
+        # the kernel-trace average of the same loop from the committed profile (HIP events around dcm_step vary by 3 us from box to
+        # box; the kernel's own duration says whether an episode end still stretches the launch)
+        cs = load_counters(f"k_step_steady:{Bs}x{A}A{T}T")
+        if cs and not staleness(cs, _lib.build_id()):
+            out["steady_state_rocprof_avg_us"] = cs.get("avg_launch_us")
+            out["terminal_flush_rocprof_avg_us"] = cs.get("flush_avg_us")
+        c4 = load_counters(f"k_step:{Bs}x{A}A{T}T")                     # ... against the window in which no episode ends
+        if c4 and not staleness(c4, _lib.build_id()):
+            out["no_episode_end_rocprof_avg_us"] = c4.get("avg_launch_us")
         env.close()
     except Exception as ex:
         out["steady_state_error"] = f"{type(ex).__name__}: {ex}"[:200]
@@ -437,7 +446,7 @@ def make_summary(out):
           "roofline": _pick(roof, "frac", "frac_hi", "salu_issue_frac", "stale"),
           "parity": _pick(par, "envs_checked", "mismatches"),
           "cpu_baseline": _pick(out.get("cpu_baseline") or {}, "value", "cores"),
-          "lockstep_kernel": _pick(lock, "envs", "frac", "traffic_frac", "rocprof_avg_launch_us", "steady_state_us", "error")}
+          "lockstep_kernel": _pick(lock, "envs", "frac", "traffic_frac", "rocprof_avg_launch_us", "steady_state_us", "steady_state_rocprof_avg_us", "no_episode_end_rocprof_avg_us", "error")}
     for name, e in (out.get("other_configs") or {}).items():
         if not isinstance(e, dict):
             continue

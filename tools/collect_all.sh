@@ -20,6 +20,19 @@ if [ -d gpurun_out/prof_${R}_steady ]; then
   cp gpurun_out/prof_${R}_steady/command.txt profiles/${R}_lockstep_steady/
   f=$(find gpurun_out/prof_${R}_steady -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "k_step|k_terminal" $f) > profiles/${R}_lockstep_steady/kernel_stats.csv
+  # ... and into counters.json (bench.py: lockstep_kernel.steady_state_rocprof_avg_us)
+  python - ${R} <<'P'
+import csv, json, sys
+R = sys.argv[1]
+rows = {("flush" if "k_terminal" in r["Name"] else "step"): r for r in csv.DictReader(open(f"profiles/{R}_lockstep_steady/kernel_stats.csv"))}
+bid = [l.split()[1] for l in open(f"gpurun_out/prof_{R}_steady/stats.log") if l.startswith("build_id ")]
+c = json.load(open("profiles/counters.json"))
+c["k_step_steady:4096x20A50T"] = dict(source=f"profiles/{R}_lockstep_steady/kernel_stats.csv", build_id=bid[-1] if bid else None,
+                                      avg_launch_us=float(rows["step"]["AverageNs"]) / 1e3, launches=int(rows["step"]["Calls"]),
+                                      flush_avg_us=float(rows["flush"]["AverageNs"]) / 1e3 if "flush" in rows else None,
+                                      flush_launches=int(rows["flush"]["Calls"]) if "flush" in rows else 0)
+json.dump(c, open("profiles/counters.json", "w"), indent=1, sort_keys=True)
+P
 fi
 for f in bench bench_config4 bench_config5 bench_config5_generalised bench_config5_static; do
   [ -s gpurun_out/${R}_$f.json ] && grep '^{' gpurun_out/${R}_$f.json | tail -1 > profiles/${R}_$f.json
